@@ -1,0 +1,103 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's
+ * collide-then-stream hot path.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product
+ * (lattice-boltzmann-method_amd/) never links, imports or calls it.
+ *
+ * Layout is the REFERENCE layout (AoS, q innermost): f[R][C][9], rho[R][C],
+ * u[R][C][2]; f64 everywhere.  Every function cites the reference lines it
+ * restates.  Pinning status per function: see oracle/README.md.
+ */
+#ifndef LBM_ORACLE_H
+#define LBM_ORACLE_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int  orc_max_threads(void);
+void orc_set_threads(int n);
+
+/* ---- solver:: (src/solver.cpp:23-131) ---- */
+void orc_calc_rho(double* rho, const double* f, int R, int C);
+void orc_calc_u(double* u, const double* f, const double* rho, int R, int C);
+void orc_calc_incomp_u(double* u, const double* f, int R, int C);
+void orc_equilibrium(double* feq, const double* u, const double* rho, int R, int C);
+void orc_incomp_equilibrium(double* feq, const double* u, const double* rho, int R, int C);
+void orc_collision(double* fc, const double* f, const double* feq, double omega, int R, int C);
+void orc_advect(double* g, const double* f, int R, int C);
+
+/* BGK periodic box loop: calc_rho, calc_(incomp_)u, (incomp_)equilibrium, collision, advect. */
+void orc_bgk_periodic_steps(double* f, double* rho_out, double* u_out, int R, int C,
+                            double omega, int incompressible, int nsteps);
+
+/* ---- test/horizontal_poiseuille_test.cpp:47-175 (H, W, T parametrised) ---- */
+typedef struct {
+  int H, W, T;
+  double omega, u_max, rho_inlet, rho_outlet;
+  int check_convergence; /* reproduce :113-126 early exit */
+} orc_hpt_params;
+/* returns the number of steps executed; f/u/rho = state when the loop ended. */
+int orc_hpt_run(const orc_hpt_params* p, double* f, double* u, double* rho, double* l2_out);
+
+/* ---- test/decompose_domain.cpp:75-188: two blocks A (upstream) and B ---- */
+void orc_ddm_run(int H, int W, int T, double omega, double rho_inlet, double rho_outlet,
+                 double* fA, double* fB, double* uA, double* uB, double* rhoA, double* rhoB);
+
+/* ---- ulbm::d2q9::kbc (src/ulbm.cpp:91-320) ---- */
+/* feq from (m0, ux, uy) with the caller-supplied ux2/uy2 (the ctor leaves them 0
+ * for the driver's initialisation, ulbm_double_shear_flow.cpp:96). */
+void orc_kbc_equilibrium(double* feq, const double* m0, const double* m1,
+                         int use_zero_u2, int R, int C);
+void orc_kbc_collide(double* coll, const double* f, const double* m0, const double* m1,
+                     double s2, int R, int C, double* gamma_out);
+/* collide, advect, moment update (ulbm_double_shear_flow.cpp:119-142). */
+void orc_kbc_steps(double* f, double* m0, double* m1, int R, int C, double s2, int nsteps);
+/* shear-layer IC, ulbm_double_shear_flow.cpp:42-63 */
+void orc_kbc_shear_init(double* m0, double* m1, int R, int C, double u_max,
+                        double alpha, double delta);
+
+/* ---- differential (src/differential.hpp:9-40, src/differential.cpp:3-33) ---- */
+void orc_diff_x(double* out, const double* psi, int R, int C);
+void orc_diff_y(double* out, const double* psi, int R, int C);
+
+/* ---- colour-gradient MRT two-phase step (test/mrtcg_rayleigh_taylor.cpp) ---- */
+typedef struct {
+  double rho_0, alpha, nu, beta; /* [red]/[blue] TOML keys, src/colour.cpp:11-20 */
+} orc_colour_params;
+typedef struct {
+  int R, C;
+  orc_colour_params red, blue;
+  double sigma, gravity; /* [general] sigma, gravity_magnitude (:360-361) */
+  double delta;          /* hard-coded 0.1 at :375 */
+} orc_cg_params;
+/* init_rho_cosine + feq init (:182-210, :372-373, :407-410): fills f_r, f_b (adv_f),
+ * rho_r, rho_b, u (= 0). */
+void orc_cg_init(const orc_cg_params* p, double* f_r, double* f_b,
+                 double* rho_r, double* rho_b, double* u);
+/* nsteps iterations of the loop body :431-477. State in/out: adv_f of both colours,
+ * rho_r, rho_b, u[R][C][2].  Optional outputs (may be NULL): psi, s_nu of the last step,
+ * col_r/col_b = post-collision populations of the last step. */
+void orc_cg_steps(const orc_cg_params* p, double* f_r, double* f_b, double* rho_r,
+                  double* rho_b, double* u, int nsteps, double* psi_out, double* snu_out,
+                  double* col_r_out, double* col_b_out);
+
+/* ---- immersed boundary (src/ibm.cpp) + cylinder driver (test/cylinder_test.cpp) ---- */
+typedef struct {
+  int n_markers;
+  const double* x; /* marker row coordinates (TOML array "x") */
+  const double* y; /* marker column coordinates */
+  int m_max;       /* ibm.hpp:25 default 5 */
+} orc_ibm_markers;
+/* ROI per ibm.cpp:104-156: rows [r0, r1), cols [c0, c1). */
+void orc_ibm_roi(const orc_ibm_markers* m, int* r0, int* r1, int* c0, int* c1);
+/* eulerian_force_density (ibm.cpp:158-190): u[X][Y][2], rho[X][Y] -> F[ROI_r][ROI_c][2]. */
+void orc_ibm_force(const orc_ibm_markers* m, const double* u, const double* rho,
+                   int X, int Y, double* F);
+/* cylinder_test.cpp:88-164 loop body, nsteps times. f in/out = f_adve; u/rho = last
+ * moments; Fs = last surface force [2]. */
+void orc_cylinder_steps(const orc_ibm_markers* m, double* f, double* u, double* rho,
+                        int X, int Y, double omega, double u_in, int nsteps, double* Fs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
