@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MLUPS and % of the HBM roofline of the fused D2Q9 BGK collide+stream
+step on a synthetic periodic box, 8192 x 8192 f64 nodes PER GPU (BASELINE.json configs[1]),
+slab-decomposed along rows over N GPUs (weak scaling) with a one-row halo exchange.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path (lbm_bgk_stream_collide) over every node of the box.
+Rank 0 prints ONE JSON line.  The timed region touches nothing under oracle/; the
+cpu_baseline leg (rank 0, N = 1 only) times the unmodified reference (oracle/_ref) or,
+failing that, the CPU restatement on a bounded sample.
+"""
+import argparse
+import ctypes as ct
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "lattice-boltzmann-method_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import pylbm  # noqa: E402
+from pylbm import _ptr  # noqa: E402
+from pylbm.slab import SlabRing  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md:36); measured copy ceiling 6290
+HBM_COPY_CEILING_GBS = 6290.0
+BYTES_PER_LUP = 144.0        # 9 f64 reads + 9 f64 writes, SURVEY 8(d)
+
+
+def taylor_green(lib, R_local, C, row0, R_global, dev, U=0.04):
+    """rho = 1, Taylor-Green vortex on the GLOBAL box; returns SoA f = feq(rho, u) [9,R,C]."""
+    r = (torch.arange(R_local, device=dev, dtype=torch.float64) + row0).view(-1, 1)
+    c = torch.arange(C, device=dev, dtype=torch.float64).view(1, -1)
+    kr, kc = 2 * math.pi / R_global, 2 * math.pi / C
+    u = torch.empty((2, R_local, C), dtype=torch.float64, device=dev)
+    u[0] = U * torch.sin(kr * r) * torch.cos(kc * c)
+    u[1] = -U * torch.cos(kr * r) * torch.sin(kc * c)
+    rho = torch.ones((R_local, C), dtype=torch.float64, device=dev)
+    f = torch.empty((9, R_local, C), dtype=torch.float64, device=dev)
+    lib.equilibrium(_ptr(f), _ptr(u), _ptr(rho), R_local, C, None)
+    return f
+
+
+def cpu_baseline(rows=1024, cols=1024, budget_s=15.0):
+    """Reference (oracle/_ref, libtorch CPU, all torch threads) on a bounded sample of the same
+    workload; the CPU restatement (OpenMP) beside it.  Checker code: never on the product path."""
+    import numpy as np
+    from pyoracle import Oracle, Ref
+    orc = Oracle()
+    rng = np.random.default_rng(0)
+    rho = np.ones((rows, cols))
+    u = 0.04 * rng.standard_normal((rows, cols, 2))
+    f0 = orc.equilibrium(u, rho)
+
+    def timed(fn, threads):
+        fn(f0, 1.2, 1)  # warm
+        t0 = time.perf_counter(); fn(f0, 1.2, 2); per = (time.perf_counter() - t0) / 2
+        n = max(2, min(200, int(budget_s / max(per, 1e-6))))
+        t0 = time.perf_counter(); fn(f0, 1.2, n); dt = time.perf_counter() - t0
+        return dict(value=round(rows * cols * n / dt / 1e6, 3), unit="MLUPS", cores=threads,
+                    sample=f"{rows}x{cols} periodic BGK f64, {n} steps in {dt:.1f} s")
+
+    port = timed(orc.bgk_periodic_steps, orc.max_threads())
+    port["kind"] = "port"
+    out = port
+    if Ref.available():
+        try:
+            ref = Ref()
+            out = timed(ref.bgk_periodic_steps, ref.num_threads())
+            out["kind"] = "reference"
+            out["port"] = port
+        except OSError as e:  # libtorch not loadable on this host
+            out["note"] = f"oracle/_ref unusable: {e}"
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows", type=int, default=8192, help="rows PER GPU")
+    ap.add_argument("--cols", type=int, default=8192)
+    ap.add_argument("--omega", type=float, default=1.2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for lbm_set_tuning")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = pylbm.Lib()
+    lib.set_device(local_rank)
+    for kv in a.tune:
+        k, v = kv.split("=")
+        lib.set_tuning(k.encode(), int(v))
+
+    R, C = a.rows, a.cols
+    prm = pylbm.BgkParams(a.omega, 0)
+    ring = SlabRing(lib, R, C, rank, world, dev, periodic=True)
+    f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
+    ring.load_precollision(f0, lambda dst, src, geom: lib.bgk_collide(
+        _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring.stream_ptr()))
+    del f0
+
+    def step_rows(dst, src, geom, bc, r0, r1):
+        lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
+                               r0, r1, None, None, ring.stream_ptr())
+
+    for _ in range(a.warmup):
+        ring.step(step_rows)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(a.steps):
+        ring.step(step_rows)
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # HIP events on the launch stream
+
+    t = torch.tensor([dt, dev_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt, dev_ms = float(t[0]), float(t[1])
+    mass = ring.mass()
+    if world > 1:
+        dist.all_reduce(mass, op=dist.ReduceOp.SUM)
+
+    if rank == 0:
+        lups = R * C * world * a.steps / dt
+        kern_ms = dev_ms / a.steps                       # avg duration of one launch (1 per step at N=1)
+        achieved = R * C * BYTES_PER_LUP / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "MLUPS (million lattice updates/sec), D2Q9 BGK periodic box, f64",
+            "value": round(lups / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{R}x{C} D2Q9 BGK periodic box per GPU, Taylor-Green init, "
+                                   f"fused collide+stream (pull, two SoA lattices), omega={a.omega}",
+                       "rows_per_gpu": R, "cols": C, "global_rows": R * world,
+                       "parallelism": f"slab{world}" if world > 1 else "single",
+                       "halo": "1 row x 3 populations per side over RCCL send/recv" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
+                         "traffic": None, "kernel": "k_stream_collide_v2<BgkModel>",
+                         "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": R * C * BYTES_PER_LUP},
+            "check": {"total_mass": float(mass), "expected_mass": float(R * C * world)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/* lbm_hip.h -- C ABI of the MI355X-native D2Q9 lattice-Boltzmann engine (liblbm_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of cristian-jfv/lattice-boltzmann-method: the
+ * collide-then-stream time step of src/solver.cpp and the variants built on it.
+ * The reference has no FFI of its own (its "API" is the C++ headers in src/ consumed by
+ * the drivers in test/); every entry point below cites the reference interface it
+ * replaces.  Plain pointers and sizes only -- no torch / HIP types in the signatures
+ * (lbm_stream_t is a hipStream_t passed as void*; NULL = the default stream).
+ *
+ * DATA LAYOUT.  The reference holds f as contiguous row-major [R][C][Q] f64 ("AoS", q
+ * innermost; src/domain.cpp:7-11).  The engine works on Structure-of-Arrays planes
+ *     f[q][r][c]   (q slowest, c fastest, f64)
+ * so that a wavefront reads 64 consecutive doubles of one population.  lbm_aos_to_soa /
+ * lbm_soa_to_aos convert bit-exactly: AoS element ((r*C)+c)*Q+q  <->  SoA q*R*C + r*C + c.
+ * Scalar fields: rho[R][C]; vector fields u[2][R][C] (component slowest).
+ * A lattice with ghost rows (multi-GPU slabs) stores planes of (R+2) rows: row index
+ * r in [-1, R] lives at plane offset (r+1)*C; see lbm_geom.
+ *
+ * All functions return 0 (LBM_OK) or a negative status and never throw; the message of
+ * the last failure on the calling thread is lbm_last_error_string().  Calls enqueue work
+ * on the given stream and return; nothing allocates inside a step call (graph-capturable).
+ */
+#ifndef LBM_HIP_H
+#define LBM_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBM_OK 0
+#define LBM_ERR_INVALID (-1) /* bad argument (shape, NULL pointer, unknown mode) */
+#define LBM_ERR_HIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define LBM_ERR_STATE (-3)   /* call not valid in the solver's current state */
+
+typedef void* lbm_stream_t;
+
+const char* lbm_last_error_string(void);
+int lbm_abi_version(void);
+/* number of visible HIP devices (0 when none); never fails */
+int lbm_device_count(void);
+int lbm_set_device(int dev);
+
+/* ---- device memory / streams / events (so a C or C++ host needs no HIP headers) ---- */
+int lbm_malloc(void** dptr, size_t bytes);
+int lbm_free(void* dptr);
+int lbm_memset(void* dptr, int value, size_t bytes, lbm_stream_t s);
+int lbm_memcpy_h2d(void* dst, const void* src, size_t bytes, lbm_stream_t s);
+int lbm_memcpy_d2h(void* dst, const void* src, size_t bytes, lbm_stream_t s);
+int lbm_memcpy_d2d(void* dst, const void* src, size_t bytes, lbm_stream_t s);
+int lbm_stream_create(lbm_stream_t* s);
+int lbm_stream_destroy(lbm_stream_t s);
+int lbm_stream_sync(lbm_stream_t s);
+int lbm_event_create(void** ev);
+int lbm_event_destroy(void* ev);
+int lbm_event_record(void* ev, lbm_stream_t s);
+int lbm_event_elapsed_ms(float* ms, void* start, void* stop); /* synchronises on stop */
+
+/* ---- layout converters (device buffers).  Q = 9 (f), 1 (rho), 2 (u) ---------------- */
+int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Q, lbm_stream_t s);
+int lbm_soa_to_aos(double* aos, const double* soa, int R, int C, int Q, lbm_stream_t s);
+
+/* ---- unfused parity operators: one per solver:: function (src/solver.hpp:11-36) -----
+ * SoA planes without ghost rows.  Unlike the reference outputs are written in
+ * place, never re-bound. */
+int lbm_calc_rho(double* rho, const double* f, int R, int C, lbm_stream_t s);                 /* solver.cpp:23-26 */
+int lbm_calc_u(double* u, const double* f, const double* rho, int R, int C, lbm_stream_t s);  /* solver.cpp:34-37 */
+int lbm_calc_incomp_u(double* u, const double* f, int R, int C, lbm_stream_t s);              /* solver.cpp:28-31 */
+int lbm_equilibrium(double* feq, const double* u, const double* rho, int R, int C, lbm_stream_t s);        /* :51-62 */
+int lbm_incomp_equilibrium(double* feq, const double* u, const double* rho, int R, int C, lbm_stream_t s); /* :39-49 */
+int lbm_collision(double* f_coll, const double* f_curr, const double* f_equi, double omega,
+                  int R, int C, lbm_stream_t s);                                              /* solver.cpp:65-74 */
+int lbm_advect(double* g, const double* f, int R, int C, lbm_stream_t s);                     /* solver.cpp:76-131 */
+
+/* ---- geometry and boundary descriptors ------------------------------------------------ */
+typedef struct lbm_geom {
+  int R;     /* rows owned by this block / slab (reference dim 0, pairs with c_x) */
+  int C;     /* columns (reference dim 1, pairs with c_y) */
+  int ghost; /* 0: planes are [R][C] and streaming wraps rows periodically inside the block
+                1: planes are [R+2][C]; rows -1 and R are ghost rows owned by the neighbours */
+} lbm_geom;
+
+/* What the reference drivers do to the populations a node cannot receive from inside the
+ * domain.  Every mode restates one driver fix-up (all applied post-streaming, reading the
+ * post-collision populations of the SAME node). */
+enum lbm_edge_mode {
+  LBM_EDGE_PERIODIC = 0,     /* nothing: solver::advect's own wrap (solver.cpp:84-128) */
+  LBM_EDGE_HALO = 1,         /* rows only: ghost row is filled by the neighbouring slab */
+  LBM_EDGE_BOUNCE_BACK = 2,  /* halfway bounce-back: horizontal_poiseuille_test.cpp:146-152 (columns),
+                                mrtcg_rayleigh_taylor.cpp:525-531 (rows) */
+  LBM_EDGE_SPECULAR = 3,     /* columns: cylinder_test.cpp:157-163 */
+  LBM_EDGE_ABB_VELOCITY = 4, /* rows: anti-bounce-back with wall velocity, cylinder_test.cpp:135-154 */
+  LBM_EDGE_WRAP_NOSHIFT = 5  /* columns, rows 1..R-2 only: the colour-gradient driver's same-row column
+                                copy, mrtcg_rayleigh_taylor.cpp:517-523 */
+};
+
+typedef struct lbm_bc {
+  int row_lo, row_hi; /* mode at global row 0 / row R-1 (enum lbm_edge_mode) */
+  int col_lo, col_hi; /* mode at column 0 / column C-1 */
+  /* pressure-periodic virtual rows, horizontal_poiseuille_test.cpp:25-45 (applied to the
+     post-collision rows 0 and R-1 before streaming): 0 = off, 1 = on, using the model's own
+     equilibrium (incompressible in that driver, compressible in decompose_domain.cpp:25-48) */
+  int pressure_rows;
+  double rho_inlet, rho_outlet;
+  double uw_r, uw_c; /* wall velocity of LBM_EDGE_ABB_VELOCITY rows (u_w, cylinder_test.cpp:73) */
+} lbm_bc;
+
+/* ---- BGK (solver.cpp:23-74 fused with :76-131) ---------------------------------------- */
+typedef struct lbm_bgk_params {
+  double omega;
+  int incompressible; /* 0: calc_u + equilibrium; 1: calc_incomp_u + incomp_equilibrium */
+} lbm_bgk_params;
+
+/* P = collide(f): moments, equilibrium, collision of every node in place of one driver
+ * iteration's calc_rho..collision calls; local, no streaming.  rho/u may be NULL. */
+int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc* bc,
+                    const lbm_bgk_params* prm, double* rho, double* u, lbm_stream_t s);
+/* The hot loop: p_new = collide(stream(p_old)) for rows [row_begin, row_end), boundary
+ * fix-ups included.  p_old holds POST-collision populations (f_coll of the reference);
+ * streaming happens at read time (pull).  rho/u (may be NULL) receive the moments of the
+ * streamed state, i.e. what calc_rho/calc_u return at the top of the next driver iteration. */
+int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
+                           const lbm_bc* bc, const lbm_bgk_params* prm, int row_begin,
+                           int row_end, double* rho, double* u, lbm_stream_t s);
+/* f = stream(p) incl. boundary fix-ups == solver::advect + the driver's post-advect BCs. */
+int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s);
+
+/* ---- KBC entropic central-moment collision (src/ulbm.cpp; BASELINE config 3) -------------- */
+typedef struct lbm_kbc_params {
+  double s2; /* ulbm::d2q9::kbc ctor argument (src/ulbm.hpp:23) */
+} lbm_kbc_params;
+/* kbc::eval_equilibrium (ulbm.cpp:248-263) on SoA m0[R][C], m1[2][R][C].  zero_u2 != 0 is the
+ * state in which the driver calls it (ux2 = uy2 = 0 from the ctor, ulbm_double_shear_flow.cpp:96) */
+int lbm_kbc_equilibrium(double* feq, const double* m0, const double* m1, int R, int C,
+                        int zero_u2, lbm_stream_t s);
+/* kbc::collide (ulbm.cpp:91-126) with the moments the caller holds (unit parity) */
+int lbm_kbc_collide_given_moments(double* coll, const double* f, const double* m0,
+                                  const double* m1, const lbm_kbc_params* prm, int R, int C,
+                                  lbm_stream_t s);
+/* as the BGK pair above: moments recomputed from the populations
+ * (ulbm_double_shear_flow.cpp:141-142), collide, (pull-)stream */
+int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc* bc,
+                    const lbm_kbc_params* prm, double* rho, double* u, lbm_stream_t s);
+int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
+                           const lbm_bc* bc, const lbm_kbc_params* prm, int row_begin,
+                           int row_end, double* rho, double* u, lbm_stream_t s);
+
+/* ---- solver context: one block, two lattices, the driver loop ----------------------------
+ * Replaces the hand-written time loops of the reference drivers (e.g.
+ * horizontal_poiseuille_test.cpp:100-153).  The context keeps POST-collision populations
+ * resident and streams at read time, so n driver iterations cost one collide-only launch
+ * plus n-1 fused launches; get_f streams lazily and returns the reference's f_adve. */
+typedef struct lbm_solver lbm_solver;
+enum lbm_model { LBM_MODEL_BGK = 0, LBM_MODEL_KBC = 1 };
+
+int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_bc* bc,
+                      const void* params /* lbm_bgk_params* or lbm_kbc_params* */, lbm_stream_t s);
+int lbm_solver_destroy(lbm_solver* sv);
+/* f_adve of the reference, host AoS [R][C][9] */
+int lbm_solver_set_f_aos(lbm_solver* sv, const double* f_host);
+int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host);
+/* same, device SoA [9][R][C] (no ghost rows) */
+int lbm_solver_set_f_soa_dev(lbm_solver* sv, const double* f_dev);
+int lbm_solver_get_f_soa_dev(lbm_solver* sv, double* f_dev);
+/* n driver iterations; record_moments != 0: the last one also stores rho/u exactly as the
+ * reference's rho/u tensors hold them when its loop has run n iterations */
+int lbm_solver_step(lbm_solver* sv, int n, int record_moments);
+/* host AoS rho[R][C], u[R][C][2] recorded by the last step(.., 1) */
+int lbm_solver_get_moments_aos(lbm_solver* sv, double* rho_host, double* u_host);
+int lbm_solver_sync(lbm_solver* sv);
+/* device pointers of the resident lattices (current post-collision, scratch) for callers
+ * that drive lbm_*_stream_collide themselves (benchmarks, multi-GPU slabs) */
+int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other);
+
+/* kernel-variant selector for lbm_bgk_stream_collide's interior path (tuning / tests):
+ * 0 = default.  See DESIGN.md "BGK kernel variants". */
+int lbm_set_tuning(const char* key, int value);
+int lbm_get_tuning(const char* key);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBM_HIP_H */

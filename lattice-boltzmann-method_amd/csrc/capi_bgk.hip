@@ -1,0 +1,115 @@
+// C ABI, part 2: the BGK hot loop (solver.cpp:23-131 fused) and stream-only.
+#include "launch.hpp"
+
+namespace lbm {
+
+// Pressure-periodic virtual rows (horizontal_poiseuille_test.cpp:25-45; compressible variant
+// decompose_domain.cpp:25-48): the post-collision populations of row 0 are replaced by
+//   feq(rho_inlet, u[R-2]) + f_coll[R-2] - f_equi[R-2]
+// and those of row R-1 by feq(rho_outlet, u[1]) + f_coll[1] - f_equi[1].  The source node is
+// re-collided here with exactly the arithmetic of the main kernel, so f_coll and f_equi are
+// the values the reference holds.  One thread per (edge, column).
+template <bool FROM_POST>
+__global__ __launch_bounds__(256) void k_bgk_pressure_rows(double* __restrict__ pn,
+                                                           const double* __restrict__ in, Geom g,
+                                                           Bc bc, BgkModel m) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * g.C) return;
+  const int e = i / g.C, c = i % g.C;
+  const int dst = e ? g.R - 1 : 0, src = e ? 1 : g.R - 2;
+  const double rho_bc = (e ? bc.rho_outlet : bc.rho_inlet) * 1.0;
+  double f[Q], feq[Q], te[Q], rho, ux, uy;
+  if (FROM_POST) {
+    gather_bc(f, in, g, bc, src, c);
+  } else {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) f[q] = in[q * g.plane + g.at(src, c)];
+  }
+  m.collide(f, rho, ux, uy, feq);
+  m.feq(te, rho_bc, ux, uy);
+  const long o = g.at(dst, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) pn[q * g.plane + o] = (te[q] + f[q]) - feq[q];
+}
+
+// f = stream(p) with all boundary fix-ups (solver::advect + post-advect BCs).
+__global__ __launch_bounds__(256) void k_stream_only(double* __restrict__ f,
+                                                     const double* __restrict__ p, Geom g, Bc bc) {
+  const long n_nodes = (long)g.R * g.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes;
+       i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / g.C), c = (int)(i % g.C);
+    double v[Q];
+    gather_bc(v, p, g, bc, r, c);
+    const long o = g.at(r, c);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) f[q * g.plane + o] = v[q];
+  }
+}
+
+static int launch_pressure_rows(bool from_post, double* pn, const double* in, const Geom& g,
+                                const Bc& bc, const BgkModel& m, hipStream_t st) {
+  const int n = 2 * g.C;
+  if (from_post) LBM_KLAUNCH(k_bgk_pressure_rows<true>, dim3((n + 255) / 256), dim3(256), 0, st, pn, in, g, bc, m);
+  else LBM_KLAUNCH(k_bgk_pressure_rows<false>, dim3((n + 255) / 256), dim3(256), 0, st, pn, in, g, bc, m);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+static int check_bgk(const char* fn, const lbm_bgk_params* prm) {
+  LBM_REQUIRE(prm, "%s: NULL params", fn);
+  LBM_REQUIRE(prm->omega > 0.0 && prm->omega < 2.0, "%s: omega=%g outside (0, 2)", fn, prm->omega);
+  return LBM_OK;
+}
+
+}  // namespace lbm
+
+using namespace lbm;
+
+extern "C" {
+
+int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc* bc,
+                    const lbm_bgk_params* prm, double* rho, double* u, lbm_stream_t s) {
+  int rc = check_bgk("lbm_bgk_collide", prm);
+  if (rc) return rc;
+  const BgkModel m{prm->omega, prm->incompressible};
+  rc = launch_collide_only("lbm_bgk_collide", p, f, g, bc, m, rho, u, as_stream(s));
+  if (rc) return rc;
+  if (bc && bc->pressure_rows) {
+    LBM_REQUIRE(p != f, "lbm_bgk_collide: pressure rows need distinct in/out lattices");
+    LBM_REQUIRE(g->ghost == 0, "lbm_bgk_collide: pressure rows are single-block only");
+    return launch_pressure_rows(false, p, f, make_geom(*g), make_bc(bc), m, as_stream(s));
+  }
+  return LBM_OK;
+}
+
+int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
+                           const lbm_bc* bc, const lbm_bgk_params* prm, int row_begin,
+                           int row_end, double* rho, double* u, lbm_stream_t s) {
+  int rc = check_bgk("lbm_bgk_stream_collide", prm);
+  if (rc) return rc;
+  const BgkModel m{prm->omega, prm->incompressible};
+  rc = launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, m, row_begin, row_end,
+                             rho, u, as_stream(s));
+  if (rc) return rc;
+  if (bc && bc->pressure_rows) {
+    LBM_REQUIRE(g->ghost == 0 && row_begin == 0 && row_end == g->R,
+                "lbm_bgk_stream_collide: pressure rows need the whole single block");
+    return launch_pressure_rows(true, p_new, p_old, make_geom(*g), make_bc(bc), m, as_stream(s));
+  }
+  return LBM_OK;
+}
+
+int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s) {
+  int rc = validate_geom_bc("lbm_stream", g, bc);
+  if (rc) return rc;
+  LBM_REQUIRE(f && p && f != p, "lbm_stream: NULL or aliased lattices");
+  const Geom gg = make_geom(*g);
+  const long n = (long)gg.R * gg.C;
+  LBM_KLAUNCH(k_stream_only, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s),
+                     f, p, gg, make_bc(bc));
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,283 @@
+// C ABI, part 1: status, device memory/stream/event helpers, layout converters and the
+// seven unfused solver:: operators (parity surface, not the hot path).
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "d2q9.hpp"
+#include "internal.hpp"
+
+namespace lbm {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+static std::mutex g_tune_mu;
+static std::map<std::string, int> g_tune;
+
+int tuning(const char* key, int dflt) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  auto it = g_tune.find(key);
+  return it == g_tune.end() ? dflt : it->second;
+}
+
+// ---- layout converters -------------------------------------------------------------------
+// AoS [n][Q] <-> SoA [Q][n].  A 256-thread block moves a tile of 256 nodes through LDS so that
+// both the AoS side (Q*256 consecutive doubles) and the SoA side (256 consecutive doubles
+// per plane) are coalesced.  Leading dimension Q+... padding is unnecessary: Q is odd (9)
+// or tiny (1, 2).
+template <bool TO_SOA>
+__global__ __launch_bounds__(256) void k_layout(double* __restrict__ dst,
+                                                const double* __restrict__ src, long n, int Qn) {
+  extern __shared__ double tile[];  // [256 * Qn]
+  for (long base = (long)blockIdx.x * 256; base < n; base += (long)gridDim.x * 256) {
+    const int cnt = (int)((n - base) < 256 ? (n - base) : 256);
+    if (TO_SOA) {
+      for (int i = threadIdx.x; i < cnt * Qn; i += 256) tile[i] = src[base * Qn + i];
+      __syncthreads();
+      if ((int)threadIdx.x < cnt)
+        for (int q = 0; q < Qn; ++q) dst[(long)q * n + base + threadIdx.x] = tile[threadIdx.x * Qn + q];
+    } else {
+      if ((int)threadIdx.x < cnt)
+        for (int q = 0; q < Qn; ++q) tile[threadIdx.x * Qn + q] = src[(long)q * n + base + threadIdx.x];
+      __syncthreads();
+      for (int i = threadIdx.x; i < cnt * Qn; i += 256) dst[base * Qn + i] = tile[i];
+    }
+    __syncthreads();
+  }
+}
+
+// ---- unfused operators (SoA, no ghost rows) ----------------------------------------------
+__global__ __launch_bounds__(256) void k_calc_rho(double* __restrict__ rho,
+                                                  const double* __restrict__ f, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double v[Q], r, jx, jy;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = f[q * n + i];
+    BgkModel::moments(v, r, jx, jy);
+    rho[i] = r;
+  }
+}
+template <bool INCOMP>
+__global__ __launch_bounds__(256) void k_calc_u(double* __restrict__ u, const double* __restrict__ f,
+                                                const double* __restrict__ rho, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double v[Q], r, jx, jy;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = f[q * n + i];
+    BgkModel::moments(v, r, jx, jy);
+    if (INCOMP) {
+      u[i] = jx;
+      u[n + i] = jy;
+    } else {
+      const double d = rho[i];  // the reference divides by the rho it is GIVEN (solver.cpp:36)
+      u[i] = jx / d;
+      u[n + i] = jy / d;
+    }
+  }
+}
+template <bool INCOMP>
+__global__ __launch_bounds__(256) void k_equilibrium(double* __restrict__ feq,
+                                                     const double* __restrict__ u,
+                                                     const double* __restrict__ rho, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double e[Q];
+    if (INCOMP) BgkModel::feq_incomp(e, rho[i], u[i], u[n + i]);
+    else BgkModel::feq_comp(e, rho[i], u[i], u[n + i]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) feq[q * n + i] = e[q];
+  }
+}
+__global__ __launch_bounds__(256) void k_collision(double* __restrict__ fc,
+                                                   const double* __restrict__ f,
+                                                   const double* __restrict__ fe, double omega,
+                                                   long n9) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n9; i += (long)gridDim.x * 256)
+    fc[i] = (1.0 - omega) * f[i] + omega * fe[i];  // solver.cpp:73
+}
+
+}  // namespace lbm
+
+using namespace lbm;
+
+extern "C" {
+
+const char* lbm_last_error_string(void) { return g_err; }
+int lbm_abi_version(void) { return 1; }
+
+int lbm_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+int lbm_set_device(int dev) {
+  LBM_CHECK_HIP(hipSetDevice(dev));
+  return LBM_OK;
+}
+
+int lbm_malloc(void** dptr, size_t bytes) {
+  LBM_REQUIRE(dptr, "lbm_malloc: NULL out pointer");
+  LBM_CHECK_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+  return LBM_OK;
+}
+int lbm_free(void* dptr) {
+  if (dptr) LBM_CHECK_HIP(hipFree(dptr));
+  return LBM_OK;
+}
+int lbm_memset(void* dptr, int value, size_t bytes, lbm_stream_t s) {
+  LBM_CHECK_HIP(hipMemsetAsync(dptr, value, bytes, as_stream(s)));
+  return LBM_OK;
+}
+int lbm_memcpy_h2d(void* dst, const void* src, size_t bytes, lbm_stream_t s) {
+  LBM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(s)));
+  return LBM_OK;
+}
+int lbm_memcpy_d2h(void* dst, const void* src, size_t bytes, lbm_stream_t s) {
+  LBM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(s)));
+  return LBM_OK;
+}
+int lbm_memcpy_d2d(void* dst, const void* src, size_t bytes, lbm_stream_t s) {
+  LBM_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(s)));
+  return LBM_OK;
+}
+int lbm_stream_create(lbm_stream_t* s) {
+  LBM_REQUIRE(s, "lbm_stream_create: NULL out pointer");
+  hipStream_t st;
+  LBM_CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *s = st;
+  return LBM_OK;
+}
+int lbm_stream_destroy(lbm_stream_t s) {
+  LBM_CHECK_HIP(hipStreamDestroy(as_stream(s)));
+  return LBM_OK;
+}
+int lbm_stream_sync(lbm_stream_t s) {
+  LBM_CHECK_HIP(hipStreamSynchronize(as_stream(s)));
+  return LBM_OK;
+}
+int lbm_event_create(void** ev) {
+  LBM_REQUIRE(ev, "lbm_event_create: NULL out pointer");
+  hipEvent_t e;
+  LBM_CHECK_HIP(hipEventCreate(&e));
+  *ev = e;
+  return LBM_OK;
+}
+int lbm_event_destroy(void* ev) {
+  LBM_CHECK_HIP(hipEventDestroy((hipEvent_t)ev));
+  return LBM_OK;
+}
+int lbm_event_record(void* ev, lbm_stream_t s) {
+  LBM_CHECK_HIP(hipEventRecord((hipEvent_t)ev, as_stream(s)));
+  return LBM_OK;
+}
+int lbm_event_elapsed_ms(float* ms, void* start, void* stop) {
+  LBM_REQUIRE(ms, "lbm_event_elapsed_ms: NULL out pointer");
+  LBM_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));
+  LBM_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return LBM_OK;
+}
+
+int lbm_set_tuning(const char* key, int value) {
+  LBM_REQUIRE(key, "lbm_set_tuning: NULL key");
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tune[key] = value;
+  return LBM_OK;
+}
+int lbm_get_tuning(const char* key) { return key ? tuning(key, 0) : 0; }
+
+static int check_shape(const char* fn, int R, int C) {
+  LBM_REQUIRE(R > 0 && C > 0, "%s: R=%d C=%d must be positive", fn, R, C);
+  return LBM_OK;
+}
+#define SHAPE_OR_RETURN(fn)                    \
+  do {                                         \
+    int rc_ = check_shape(fn, R, C);           \
+    if (rc_) return rc_;                       \
+  } while (0)
+
+int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Qn, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_aos_to_soa");
+  LBM_REQUIRE(soa && aos && Qn >= 1 && Qn <= 16, "lbm_aos_to_soa: bad pointer or Q=%d", Qn);
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_layout<true>, dim3(capped_grid((n + 255) / 256)), dim3(256),
+                     256 * Qn * sizeof(double), as_stream(s), soa, aos, n, Qn);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_soa_to_aos(double* aos, const double* soa, int R, int C, int Qn, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_soa_to_aos");
+  LBM_REQUIRE(soa && aos && Qn >= 1 && Qn <= 16, "lbm_soa_to_aos: bad pointer or Q=%d", Qn);
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_layout<false>, dim3(capped_grid((n + 255) / 256)), dim3(256),
+                     256 * Qn * sizeof(double), as_stream(s), aos, soa, n, Qn);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_calc_rho(double* rho, const double* f, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_calc_rho");
+  LBM_REQUIRE(rho && f, "lbm_calc_rho: NULL pointer");
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_calc_rho, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), rho, f, n);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_calc_u(double* u, const double* f, const double* rho, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_calc_u");
+  LBM_REQUIRE(u && f && rho, "lbm_calc_u: NULL pointer");
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_calc_u<false>, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), u, f, rho, n);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_calc_incomp_u(double* u, const double* f, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_calc_incomp_u");
+  LBM_REQUIRE(u && f, "lbm_calc_incomp_u: NULL pointer");
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_calc_u<true>, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), u, f,
+                     (const double*)nullptr, n);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_equilibrium(double* feq, const double* u, const double* rho, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_equilibrium");
+  LBM_REQUIRE(feq && u && rho, "lbm_equilibrium: NULL pointer");
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_equilibrium<false>, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), feq, u, rho, n);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_incomp_equilibrium(double* feq, const double* u, const double* rho, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_incomp_equilibrium");
+  LBM_REQUIRE(feq && u && rho, "lbm_incomp_equilibrium: NULL pointer");
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_equilibrium<true>, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), feq, u, rho, n);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_collision(double* fc, const double* f, const double* fe, double omega, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_collision");
+  LBM_REQUIRE(fc && f && fe, "lbm_collision: NULL pointer");
+  const long n9 = (long)R * C * Q;
+  LBM_KLAUNCH(k_collision, dim3(capped_grid((n9 + 255) / 256)), dim3(256), 0, as_stream(s), fc, f, fe, omega, n9);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int lbm_advect(double* gdst, const double* f, int R, int C, lbm_stream_t s) {
+  SHAPE_OR_RETURN("lbm_advect");
+  LBM_REQUIRE(gdst && f && gdst != f, "lbm_advect: NULL or aliased pointers");
+  lbm_geom g{R, C, 0};
+  return lbm_stream(gdst, f, &g, nullptr, s);
+}
+
+}  // extern "C"

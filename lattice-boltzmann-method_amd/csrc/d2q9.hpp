@@ -1,0 +1,368 @@
+// D2Q9 device core for gfx950: lattice constants, SoA indexing, the pull-streaming gather
+// (fast interior path + boundary path) and the model-templated stream+collide kernels.
+//
+// Conventions (SURVEY.md naming trap): W = the reference's solver::E (weights,
+// src/solver.cpp:12-16); (CX, CY) = solver::c rows 0/1 (:18-21).  CX pairs with the row
+// index r, CY with the column index c.  All arithmetic is f64 and the translation unit is
+// built with -ffp-contract=off: every expression below is evaluated in the order the
+// reference writes it, so results agree with the CPU oracle to the last bit wherever the
+// oracle itself is order-deterministic.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/lbm_hip.h"
+
+namespace lbm {
+
+constexpr int Q = 9;
+
+#define LBM_W0 (4.0 / 9.0)
+#define LBM_WS (1.0 / 9.0)
+#define LBM_WD (1.0 / 36.0)
+
+__device__ __forceinline__ constexpr double wq(int q) {
+  return q == 0 ? LBM_W0 : (q < 5 ? LBM_WS : LBM_WD);
+}
+__host__ __device__ __forceinline__ constexpr int icx(int q) {
+  return (q == 1 || q == 5 || q == 8) ? 1 : ((q == 3 || q == 6 || q == 7) ? -1 : 0);
+}
+__host__ __device__ __forceinline__ constexpr int icy(int q) {
+  return (q == 2 || q == 5 || q == 6) ? 1 : ((q == 4 || q == 7 || q == 8) ? -1 : 0);
+}
+__host__ __device__ __forceinline__ constexpr int opp(int q) {
+  return q == 0 ? 0 : (q == 1 ? 3 : (q == 2 ? 4 : (q == 3 ? 1 : (q == 4 ? 2 : (q == 5 ? 7 : (q == 6 ? 8 : (q == 7 ? 5 : 6)))))));
+}
+
+// Geometry of one SoA lattice (device copy of lbm_geom + derived strides).
+struct Geom {
+  int R, C, ghost;
+  long plane;  // doubles per population plane = (R + 2*ghost) * C
+  __host__ __device__ long at(int r, int c) const { return (long)(r + ghost) * C + c; }
+};
+inline Geom make_geom(const lbm_geom& g) {
+  return Geom{g.R, g.C, g.ghost, (long)(g.R + 2 * g.ghost) * g.C};
+}
+
+struct Bc {
+  int row_lo, row_hi, col_lo, col_hi, pressure_rows;
+  double rho_inlet, rho_outlet, uw_r, uw_c;
+};
+inline Bc make_bc(const lbm_bc* b) {
+  if (!b) return Bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
+  return Bc{b->row_lo, b->row_hi, b->col_lo, b->col_hi, b->pressure_rows,
+            b->rho_inlet, b->rho_outlet, b->uw_r, b->uw_c};
+}
+inline bool bc_needs_edge_pass(const Bc& b) {
+  auto active = [](int m) { return m != LBM_EDGE_PERIODIC && m != LBM_EDGE_HALO; };
+  return active(b.row_lo) || active(b.row_hi) || active(b.col_lo) || active(b.col_hi);
+}
+
+// ---------------------------------------------------------------------------------------
+// Streaming (pull form of solver::advect, src/solver.cpp:76-131):
+//   g_q(r, c) = f_q((r - cx_q) mod R, (c - cy_q) mod C)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int wrap_row(const Geom& g, int r) {
+  if (g.ghost) return r;  // ghost rows -1 and R exist
+  return r < 0 ? r + g.R : (r >= g.R ? r - g.R : r);
+}
+__device__ __forceinline__ int wrap_col(const Geom& g, int c) {
+  return c < 0 ? c + g.C : (c >= g.C ? c - g.C : c);
+}
+
+// Generic gather of the 9 incoming populations of node (r, c), including every boundary
+// fix-up the reference drivers apply after advect().  Slow path: used for
+// boundary nodes only and by the small-lattice kernels.
+__device__ inline void gather_bc(double (&f)[Q], const double* __restrict__ p, const Geom& g,
+                                 const Bc& bc, int r, int c) {
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    f[q] = p[q * g.plane + g.at(wrap_row(g, r - icx(q)), wrap_col(g, c - icy(q)))];
+  const long own = g.at(r, c);
+#define OWN(q) p[(q) * g.plane + own]
+  // rows first (cylinder_test.cpp applies its inlet/outlet rows before the side walls) ...
+  const bool lo = (r == 0), hi = (r == g.R - 1);
+  if (lo && bc.row_lo == LBM_EDGE_BOUNCE_BACK) {  // mrtcg_rayleigh_taylor.cpp:529-531
+    f[1] = OWN(3); f[5] = OWN(7); f[8] = OWN(6);
+  }
+  if (hi && bc.row_hi == LBM_EDGE_BOUNCE_BACK) {  // :525-527
+    f[3] = OWN(1); f[7] = OWN(5); f[6] = OWN(8);
+  }
+  if ((lo && bc.row_lo == LBM_EDGE_ABB_VELOCITY) || (hi && bc.row_hi == LBM_EDGE_ABB_VELOCITY)) {
+    // cylinder_test.cpp:135-154: f[opp(q)] = -f_coll[q] + (2 + 9 (c_q.u_w)^2 - 3 u_w.u_w) w_q
+    const double uu = bc.uw_r * bc.uw_r + bc.uw_c * bc.uw_c;
+#pragma unroll
+    for (int q = 1; q < Q; ++q) {
+      const double cu = bc.uw_r * (double)icx(q) + bc.uw_c * (double)icy(q);
+      const double abb = (2.0 + 9.0 * (cu * cu) - 3.0 * uu) * wq(q);
+      f[opp(q)] = -OWN(q) + abb;
+    }
+  }
+  // ... then columns (they win at the corners, as in the drivers)
+  if (c == g.C - 1) {
+    if (bc.col_hi == LBM_EDGE_BOUNCE_BACK) {  // horizontal_poiseuille_test.cpp:146-148
+      f[4] = OWN(2); f[7] = OWN(5); f[8] = OWN(6);
+    } else if (bc.col_hi == LBM_EDGE_SPECULAR) {  // cylinder_test.cpp:157-159
+      f[4] = OWN(2); f[7] = OWN(6); f[8] = OWN(5);
+    } else if (bc.col_hi == LBM_EDGE_WRAP_NOSHIFT) {  // mrtcg_rayleigh_taylor.cpp:521-523
+      const bool skip = (lo && bc.row_lo != LBM_EDGE_HALO) || (hi && bc.row_hi != LBM_EDGE_HALO);
+      if (!skip) {
+        const long o = g.at(r, 0);
+        f[4] = p[4 * g.plane + o]; f[8] = p[8 * g.plane + o]; f[7] = p[7 * g.plane + o];
+      }
+    }
+  }
+  if (c == 0) {
+    if (bc.col_lo == LBM_EDGE_BOUNCE_BACK) {  // :150-152
+      f[2] = OWN(4); f[5] = OWN(7); f[6] = OWN(8);
+    } else if (bc.col_lo == LBM_EDGE_SPECULAR) {  // cylinder_test.cpp:161-163
+      f[2] = OWN(4); f[5] = OWN(8); f[6] = OWN(7);
+    } else if (bc.col_lo == LBM_EDGE_WRAP_NOSHIFT) {  // mrtcg_rayleigh_taylor.cpp:517-519
+      const bool skip = (lo && bc.row_lo != LBM_EDGE_HALO) || (hi && bc.row_hi != LBM_EDGE_HALO);
+      if (!skip) {
+        const long o = g.at(r, g.C - 1);
+        f[2] = p[2 * g.plane + o]; f[5] = p[5 * g.plane + o]; f[6] = p[6 * g.plane + o];
+      }
+    }
+  }
+#undef OWN
+}
+
+__device__ __forceinline__ bool is_edge_node(const Geom& g, int r, int c) {
+  return r == 0 || r == g.R - 1 || c == 0 || c == g.C - 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// BGK collision model (solver.cpp:23-74 per node)
+// ---------------------------------------------------------------------------------------
+struct BgkModel {
+  double omega;
+  int incompressible;
+
+  __device__ __forceinline__ static void moments(const double (&f)[Q], double& rho, double& jx,
+                                                 double& jy) {
+    // calc_rho: sum over q in index order.  matmul(f, c^T): the zero products add +-0.
+    rho = ((((((((f[0] + f[1]) + f[2]) + f[3]) + f[4]) + f[5]) + f[6]) + f[7]) + f[8]);
+    jx = ((((f[1] - f[3]) + f[5]) - f[6]) - f[7]) + f[8];
+    jy = ((((f[2] - f[4]) + f[5]) + f[6]) - f[7]) - f[8];
+  }
+  __device__ __forceinline__ static void feq_comp(double (&e)[Q], double rho, double ux, double uy) {
+    const double u_u = ux * ux + uy * uy;  // solver.cpp:57
+    const double cu[Q] = {0.0, ux, uy, -ux, -uy, ux + uy, -ux + uy, -ux - uy, ux - uy};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double A = 1.0 + 3.0 * cu[q] + 4.5 * (cu[q] * cu[q]) - 1.5 * u_u;  // :60
+      e[q] = (rho * A) * wq(q);                                                // :61
+    }
+  }
+  __device__ __forceinline__ static void feq_incomp(double (&e)[Q], double rho, double ux, double uy) {
+    const double cu[Q] = {0.0, ux, uy, -ux, -uy, ux + uy, -ux + uy, -ux - uy, ux - uy};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) e[q] = (rho + 3.0 * cu[q]) * wq(q);  // solver.cpp:47-48
+  }
+  __device__ __forceinline__ void feq(double (&e)[Q], double rho, double ux, double uy) const {
+    if (incompressible) feq_incomp(e, rho, ux, uy);
+    else feq_comp(e, rho, ux, uy);
+  }
+  // in: f = pre-collision populations; out: f = post-collision, moments, equilibrium
+  __device__ __forceinline__ void collide(double (&f)[Q], double& rho, double& ux, double& uy,
+                                          double (&e)[Q]) const {
+    double jx, jy;
+    moments(f, rho, jx, jy);
+    if (incompressible) {  // calc_incomp_u, solver.cpp:28-31
+      ux = jx;
+      uy = jy;
+    } else {  // calc_u, :34-37
+      ux = jx / rho;
+      uy = jy / rho;
+    }
+    feq(e, rho, ux, uy);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) f[q] = (1.0 - omega) * f[q] + omega * e[q];  // :73
+  }
+  __device__ __forceinline__ void collide(double (&f)[Q], double& rho, double& ux, double& uy) const {
+    double e[Q];
+    collide(f, rho, ux, uy, e);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Kernels
+// ---------------------------------------------------------------------------------------
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+// 16-byte vector with only 8-byte alignment: the +-1-column shifted reads of the pull step
+typedef double dbl2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <bool NT>
+__device__ __forceinline__ void store2(double* p, double a, double b) {
+  dbl2 v = {a, b};
+  if (NT) __builtin_nontemporal_store(v, reinterpret_cast<dbl2*>(p));
+  else *reinterpret_cast<dbl2*>(p) = v;
+}
+template <bool NT>
+__device__ __forceinline__ dbl2 load2a(const double* p) {
+  if (NT) return __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(p));
+  return *reinterpret_cast<const dbl2*>(p);
+}
+template <bool NT>
+__device__ __forceinline__ dbl2 load2u(const double* p) {
+  if (NT) {
+    dbl2u v = __builtin_nontemporal_load(reinterpret_cast<const dbl2u*>(p));
+    return dbl2{v.x, v.y};
+  }
+  dbl2u v = *reinterpret_cast<const dbl2u*>(p);
+  return dbl2{v.x, v.y};
+}
+
+// Fused pull step, interior fast path.  One thread updates two column-adjacent nodes
+// (16 B per lane per population); a block walks (row, column-tile) work items with a
+// grid-stride loop.  Column periodicity is resolved per thread (only the first and last
+// thread of a row leave the vector path); row neighbours come from wrap_row (single block
+// of rows, periodic) or from the ghost rows (slab).  Boundary fix-ups are NOT applied
+// here: k_edge_stream_collide recomputes the edge nodes afterwards.
+// Requires C % 2 == 0.
+template <class Model, bool NT_LOAD, bool NT_STORE, bool WITH_MOMENTS>
+__global__ __launch_bounds__(256) void k_stream_collide_v2(
+    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
+    int row_end, int tiles_per_row, double* __restrict__ rho_out, double* __restrict__ u_out) {
+  const long items = (long)(row_end - row_begin) * tiles_per_row;
+  for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    const int r = row_begin + (int)(it / tiles_per_row);
+    const int c = ((int)(it % tiles_per_row) * 256 + threadIdx.x) * 2;
+    if (c >= g.C) continue;
+    const long rm = g.at(wrap_row(g, r - 1), 0);  // source row of cx = +1 populations
+    const long r0 = g.at(r, 0);
+    const long rp = g.at(wrap_row(g, r + 1), 0);  // source row of cx = -1 populations
+    double a[Q], b[Q];                            // node (r, c) and node (r, c + 1)
+    dbl2 v;
+    v = load2a<NT_LOAD>(po + 0 * g.plane + r0 + c); a[0] = v.x; b[0] = v.y;
+    v = load2a<NT_LOAD>(po + 1 * g.plane + rm + c); a[1] = v.x; b[1] = v.y;
+    v = load2a<NT_LOAD>(po + 3 * g.plane + rp + c); a[3] = v.x; b[3] = v.y;
+    if (c > 0 && c + 2 < g.C) {
+      v = load2u<NT_LOAD>(po + 2 * g.plane + r0 + c - 1); a[2] = v.x; b[2] = v.y;
+      v = load2u<NT_LOAD>(po + 5 * g.plane + rm + c - 1); a[5] = v.x; b[5] = v.y;
+      v = load2u<NT_LOAD>(po + 6 * g.plane + rp + c - 1); a[6] = v.x; b[6] = v.y;
+      v = load2u<NT_LOAD>(po + 4 * g.plane + r0 + c + 1); a[4] = v.x; b[4] = v.y;
+      v = load2u<NT_LOAD>(po + 7 * g.plane + rp + c + 1); a[7] = v.x; b[7] = v.y;
+      v = load2u<NT_LOAD>(po + 8 * g.plane + rm + c + 1); a[8] = v.x; b[8] = v.y;
+    } else {
+      const int cm = wrap_col(g, c - 1), cp = wrap_col(g, c + 2);
+      a[2] = po[2 * g.plane + r0 + cm]; b[2] = po[2 * g.plane + r0 + c];
+      a[5] = po[5 * g.plane + rm + cm]; b[5] = po[5 * g.plane + rm + c];
+      a[6] = po[6 * g.plane + rp + cm]; b[6] = po[6 * g.plane + rp + c];
+      a[4] = po[4 * g.plane + r0 + c + 1]; b[4] = po[4 * g.plane + r0 + cp];
+      a[7] = po[7 * g.plane + rp + c + 1]; b[7] = po[7 * g.plane + rp + cp];
+      a[8] = po[8 * g.plane + rm + c + 1]; b[8] = po[8 * g.plane + rm + cp];
+    }
+    double rho_a, ux_a, uy_a, rho_b, ux_b, uy_b;
+    m.collide(a, rho_a, ux_a, uy_a);
+    m.collide(b, rho_b, ux_b, uy_b);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) store2<NT_STORE>(pn + q * g.plane + r0 + c, a[q], b[q]);
+    if (WITH_MOMENTS) {
+      const long o = (long)r * g.C + c;  // moment fields carry no ghost rows
+      const long n = (long)g.R * g.C;
+      store2<false>(rho_out + o, rho_a, rho_b);
+      store2<false>(u_out + o, ux_a, ux_b);
+      store2<false>(u_out + n + o, uy_a, uy_b);
+    }
+  }
+}
+
+// One node per thread, every access a naturally aligned 8-byte load/store.
+template <class Model, bool NT_LOAD, bool NT_STORE, bool WITH_MOMENTS>
+__global__ __launch_bounds__(256) void k_stream_collide_v1(
+    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
+    int row_end, int tiles_per_row, double* __restrict__ rho_out, double* __restrict__ u_out) {
+  const long items = (long)(row_end - row_begin) * tiles_per_row;
+  for (long it = blockIdx.x; it < items; it += gridDim.x) {
+    const int r = row_begin + (int)(it / tiles_per_row);
+    const int c = (int)(it % tiles_per_row) * 256 + threadIdx.x;
+    if (c >= g.C) continue;
+    const long rows[3] = {g.at(wrap_row(g, r + 1), 0), g.at(r, 0), g.at(wrap_row(g, r - 1), 0)};
+    const int cols[3] = {wrap_col(g, c + 1), c, wrap_col(g, c - 1)};
+    double f[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double* src = po + q * g.plane + rows[icx(q) + 1] + cols[icy(q) + 1];
+      f[q] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+    }
+    double rho, ux, uy;
+    m.collide(f, rho, ux, uy);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      double* dst = pn + q * g.plane + rows[1] + c;
+      if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
+      else *dst = f[q];
+    }
+    if (WITH_MOMENTS) {
+      const long o = (long)r * g.C + c, n = (long)g.R * g.C;
+      rho_out[o] = rho;
+      u_out[o] = ux;
+      u_out[n + o] = uy;
+    }
+  }
+}
+
+// Edge pass: recompute the boundary nodes (rows 0 / R-1 where they carry a fix-up, columns
+// 0 / C-1 where they do) with the full boundary gather and overwrite what the interior
+// kernel stored for them.  O(R + C) nodes.
+template <class Model, bool WITH_MOMENTS>
+__global__ __launch_bounds__(256) void k_edge_stream_collide(
+    double* __restrict__ pn, const double* __restrict__ po, Geom g, Bc bc, Model m, int row_begin,
+    int row_end, double* __restrict__ rho_out, double* __restrict__ u_out) {
+  // edge list: [0, C) row 0 | [C, 2C) row R-1 | [2C, 2C+R) col 0 | [2C+R, 2C+2R) col C-1
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int r, c;
+  if (i < g.C) { r = 0; c = i; }
+  else if (i < 2 * g.C) { r = g.R - 1; c = i - g.C; }
+  else if (i < 2 * g.C + g.R) { r = i - 2 * g.C; c = 0; }
+  else if (i < 2 * g.C + 2 * g.R) { r = i - 2 * g.C - g.R; c = g.C - 1; }
+  else return;
+  if (r < row_begin || r >= row_end) return;
+  if (i >= 2 * g.C && (r == 0 || r == g.R - 1)) return;  // corners belong to the row lists
+  double f[Q], rho, ux, uy;
+  gather_bc(f, po, g, bc, r, c);
+  m.collide(f, rho, ux, uy);
+  const long o = g.at(r, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) pn[q * g.plane + o] = f[q];
+  if (WITH_MOMENTS) {
+    const long n = (long)g.R * g.C, oo = (long)r * g.C + c;
+    rho_out[oo] = rho;
+    u_out[oo] = ux;
+    u_out[n + oo] = uy;
+  }
+}
+
+// Whole-lattice generic kernel (any C, boundary gather on every node): small lattices and
+// odd column counts.  FROM_POST = true: input holds post-collision populations and is
+// streamed at read time; false: input is the pre-collision state (first iteration).
+template <class Model, bool FROM_POST, bool WITH_MOMENTS>
+__global__ __launch_bounds__(256) void k_generic_collide(
+    double* __restrict__ pn, const double* __restrict__ in, Geom g, Bc bc, Model m, int row_begin,
+    int row_end, double* __restrict__ rho_out, double* __restrict__ u_out) {
+  const long n_nodes = (long)(row_end - row_begin) * g.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_nodes;
+       i += (long)gridDim.x * blockDim.x) {
+    const int r = row_begin + (int)(i / g.C), c = (int)(i % g.C);
+    double f[Q], rho, ux, uy;
+    if (FROM_POST) {
+      gather_bc(f, in, g, bc, r, c);
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = in[q * g.plane + g.at(r, c)];
+    }
+    m.collide(f, rho, ux, uy);
+    const long o = g.at(r, c);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) pn[q * g.plane + o] = f[q];
+    if (WITH_MOMENTS) {
+      const long n = (long)g.R * g.C, oo = (long)r * g.C + c;
+      rho_out[oo] = rho;
+      u_out[oo] = ux;
+      u_out[n + oo] = uy;
+    }
+  }
+}
+
+}  // namespace lbm

@@ -1,0 +1,53 @@
+// Host-side plumbing shared by the C-ABI translation units: per-thread error record,
+// HIP status checks, launch-geometry helpers and the tuning table.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/lbm_hip.h"
+
+namespace lbm {
+
+void set_error(const char* fmt, ...);
+int tuning(const char* key, int dflt);
+
+#define LBM_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ::lbm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                       __LINE__);                                                        \
+      return LBM_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+#define LBM_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      ::lbm::set_error(__VA_ARGS__);  \
+      return LBM_ERR_INVALID;         \
+    }                                 \
+  } while (0)
+
+#define LBM_CHECK_LAUNCH() LBM_CHECK_HIP(hipGetLastError())
+
+// Launch with the thread's sticky error cleared first: the host process (e.g. PyTorch) may
+// have left an unrelated, already-handled error behind that hipGetLastError would report.
+#define LBM_KLAUNCH(...)               \
+  do {                                 \
+    (void)hipGetLastError();           \
+    hipLaunchKernelGGL(__VA_ARGS__);   \
+  } while (0)
+
+inline hipStream_t as_stream(lbm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Grid for a memory-bound grid-stride kernel: enough blocks to fill 256 CUs x 8, no more
+// (cdna_hip_programming.md Guideline 11).
+inline int capped_grid(long work_items, int cap = 2048) {
+  if (work_items < 1) work_items = 1;
+  return (int)(work_items < cap ? work_items : cap);
+}
+
+}  // namespace lbm

@@ -1,0 +1,111 @@
+// Host-side launch logic shared by the single-phase models (BGK, KBC): choose the interior
+// variant, launch it, then the edge pass that applies the boundary fix-ups.
+#pragma once
+#include "d2q9.hpp"
+#include "internal.hpp"
+
+namespace lbm {
+
+inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc) {
+  LBM_REQUIRE(g, "%s: NULL geometry", fn);
+  LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
+  LBM_REQUIRE(g->ghost == 0 || g->ghost == 1, "%s: ghost=%d must be 0 or 1", fn, g->ghost);
+  if (bc) {
+    auto row_ok = [](int m) {
+      return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || m == LBM_EDGE_BOUNCE_BACK ||
+             m == LBM_EDGE_ABB_VELOCITY;
+    };
+    auto col_ok = [](int m) {
+      return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_BOUNCE_BACK || m == LBM_EDGE_SPECULAR ||
+             m == LBM_EDGE_WRAP_NOSHIFT;
+    };
+    LBM_REQUIRE(row_ok(bc->row_lo) && row_ok(bc->row_hi), "%s: unsupported row edge mode %d/%d", fn,
+                bc->row_lo, bc->row_hi);
+    LBM_REQUIRE(col_ok(bc->col_lo) && col_ok(bc->col_hi), "%s: unsupported column edge mode %d/%d",
+                fn, bc->col_lo, bc->col_hi);
+    LBM_REQUIRE(bc->pressure_rows == 0 || bc->pressure_rows == 1, "%s: pressure_rows=%d", fn,
+                bc->pressure_rows);
+    LBM_REQUIRE(!bc->pressure_rows || g->R >= 3, "%s: pressure rows need R >= 3", fn);
+    if (g->ghost == 0)
+      LBM_REQUIRE(bc->row_lo != LBM_EDGE_HALO && bc->row_hi != LBM_EDGE_HALO,
+                  "%s: HALO rows need ghost=1", fn);
+  }
+  return LBM_OK;
+}
+
+// p_new = collide(stream(p_old)) on rows [row_begin, row_end).
+template <class Model>
+int launch_stream_collide(const char* fn, double* pn, const double* po, const lbm_geom* lg,
+                          const lbm_bc* lbc, const Model& m, int row_begin, int row_end,
+                          double* rho, double* u, hipStream_t st) {
+  int rc = validate_geom_bc(fn, lg, lbc);
+  if (rc) return rc;
+  LBM_REQUIRE(pn && po && pn != po, "%s: NULL or aliased lattices", fn);
+  LBM_REQUIRE((rho == nullptr) == (u == nullptr), "%s: rho and u must both be given or both NULL", fn);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R,
+              "%s: row range [%d, %d) outside [0, %d)", fn, row_begin, row_end, lg->R);
+  if (row_begin == row_end) return LBM_OK;
+  const Geom g = make_geom(*lg);
+  const Bc bc = make_bc(lbc);
+  const bool mom = rho != nullptr;
+  const int nrows = row_end - row_begin;
+  const int variant = tuning("variant", 2);
+  const bool fast = (g.C % 2 == 0) && g.C >= 64 && variant != 0;
+
+  if (!fast) {  // generic path: boundary gather on every node
+    const long n = (long)nrows * g.C;
+    const int grid = capped_grid((n + 255) / 256);
+    if (mom) LBM_KLAUNCH((k_generic_collide<Model, true, true>), dim3(grid), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
+    else LBM_KLAUNCH((k_generic_collide<Model, true, false>), dim3(grid), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
+    LBM_CHECK_LAUNCH();
+    return LBM_OK;
+  }
+
+  const int nt = tuning("nt", 0);  // bit 0: non-temporal loads, bit 1: non-temporal stores
+  const int cap = tuning("grid_cap", 0);
+#define LBM_LAUNCH_VARIANT(KERNEL, NODES_PER_THREAD)                                            \
+  do {                                                                                          \
+    const int tiles = (g.C + 256 * NODES_PER_THREAD - 1) / (256 * NODES_PER_THREAD);            \
+    const long items = (long)nrows * tiles;                                                     \
+    const int grid = cap > 0 ? capped_grid(items, cap) : (int)(items < (1L << 30) ? items : (1L << 30)); \
+    switch ((nt & 3) | (mom ? 4 : 0)) {                                                         \
+      case 0: LBM_KLAUNCH((KERNEL<Model, false, false, false>), dim3(grid), dim3(256), 0, st, pn, po, g, m, row_begin, row_end, tiles, rho, u); break; \
+      case 1: LBM_KLAUNCH((KERNEL<Model, true, false, false>), dim3(grid), dim3(256), 0, st, pn, po, g, m, row_begin, row_end, tiles, rho, u); break;  \
+      case 2: LBM_KLAUNCH((KERNEL<Model, false, true, false>), dim3(grid), dim3(256), 0, st, pn, po, g, m, row_begin, row_end, tiles, rho, u); break;  \
+      case 3: LBM_KLAUNCH((KERNEL<Model, true, true, false>), dim3(grid), dim3(256), 0, st, pn, po, g, m, row_begin, row_end, tiles, rho, u); break;   \
+      default: LBM_KLAUNCH((KERNEL<Model, false, false, true>), dim3(grid), dim3(256), 0, st, pn, po, g, m, row_begin, row_end, tiles, rho, u); break; \
+    }                                                                                           \
+  } while (0)
+  if (variant == 1) LBM_LAUNCH_VARIANT(k_stream_collide_v1, 1);
+  else LBM_LAUNCH_VARIANT(k_stream_collide_v2, 2);
+#undef LBM_LAUNCH_VARIANT
+  LBM_CHECK_LAUNCH();
+
+  if (bc_needs_edge_pass(bc)) {
+    const int n_edge = 2 * g.C + 2 * g.R;
+    if (mom) LBM_KLAUNCH((k_edge_stream_collide<Model, true>), dim3((n_edge + 255) / 256), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
+    else LBM_KLAUNCH((k_edge_stream_collide<Model, false>), dim3((n_edge + 255) / 256), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
+    LBM_CHECK_LAUNCH();
+  }
+  return LBM_OK;
+}
+
+// P = collide(f) on a pre-collision lattice (first driver iteration).
+template <class Model>
+int launch_collide_only(const char* fn, double* p, const double* f, const lbm_geom* lg,
+                        const lbm_bc* lbc, const Model& m, double* rho, double* u, hipStream_t st) {
+  int rc = validate_geom_bc(fn, lg, lbc);
+  if (rc) return rc;
+  LBM_REQUIRE(p && f, "%s: NULL lattice", fn);
+  LBM_REQUIRE((rho == nullptr) == (u == nullptr), "%s: rho and u must both be given or both NULL", fn);
+  const Geom g = make_geom(*lg);
+  const Bc bc = make_bc(lbc);
+  const long n = (long)g.R * g.C;
+  const int grid = capped_grid((n + 255) / 256);
+  if (rho) LBM_KLAUNCH((k_generic_collide<Model, false, true>), dim3(grid), dim3(256), 0, st, p, f, g, bc, m, 0, g.R, rho, u);
+  else LBM_KLAUNCH((k_generic_collide<Model, false, false>), dim3(grid), dim3(256), 0, st, p, f, g, bc, m, 0, g.R, rho, u);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+}  // namespace lbm

@@ -1,0 +1,166 @@
+"""ctypes binding of liblbm_hip.so (the C ABI in include/lbm_hip.h) for tests and bench.py.
+
+The product's host side is C++ (lattice-boltzmann-method_amd/include/lbm/*.hpp, mirroring the
+reference's headers); this module is the thin Python door onto the same C ABI.  There is no
+CPU fallback: if the HIP library is missing, import fails loudly.
+"""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+REPO = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "lib", "liblbm_hip.so")
+HEADER = os.path.join(REPO, "include", "lbm_hip.h")
+
+EDGE_PERIODIC, EDGE_HALO, EDGE_BOUNCE_BACK, EDGE_SPECULAR, EDGE_ABB_VELOCITY, EDGE_WRAP_NOSHIFT = range(6)
+MODEL_BGK, MODEL_KBC = 0, 1
+
+_dp = ct.POINTER(ct.c_double)
+
+
+class Geom(ct.Structure):
+    _fields_ = [("R", ct.c_int), ("C", ct.c_int), ("ghost", ct.c_int)]
+
+
+class Bc(ct.Structure):
+    _fields_ = [("row_lo", ct.c_int), ("row_hi", ct.c_int), ("col_lo", ct.c_int),
+                ("col_hi", ct.c_int), ("pressure_rows", ct.c_int), ("rho_inlet", ct.c_double),
+                ("rho_outlet", ct.c_double), ("uw_r", ct.c_double), ("uw_c", ct.c_double)]
+
+    @staticmethod
+    def periodic():
+        return Bc(0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0)
+
+
+class BgkParams(ct.Structure):
+    _fields_ = [("omega", ct.c_double), ("incompressible", ct.c_int)]
+
+
+class KbcParams(ct.Structure):
+    _fields_ = [("s2", ct.c_double)]
+
+
+class CgColour(ct.Structure):
+    _fields_ = [("rho_0", ct.c_double), ("alpha", ct.c_double), ("nu", ct.c_double),
+                ("beta", ct.c_double)]
+
+
+class CgParams(ct.Structure):
+    _fields_ = [("red", CgColour), ("blue", CgColour), ("sigma", ct.c_double),
+                ("gravity", ct.c_double), ("delta", ct.c_double)]
+
+
+class LbmError(RuntimeError):
+    pass
+
+
+def declared_symbols(header=HEADER):
+    """Every function the C header declares (used by the ABI-completeness test)."""
+    txt = open(header).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(lbm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise LbmError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C lattice-boltzmann-method_amd/csrc` (no CPU fallback exists)")
+    lib = ct.CDLL(path)
+    lib.lbm_last_error_string.restype = ct.c_char_p
+    return lib
+
+
+class Lib:
+    """Checked calls: any non-zero status raises LbmError with the library's message."""
+
+    def __init__(self, path=LIB_PATH):
+        self.raw = load_library(path)
+
+    def __getattr__(self, name):
+        fn = getattr(self.raw, "lbm_" + name)
+
+        def call(*args):
+            rc = fn(*args)
+            if rc != 0:
+                raise LbmError(f"lbm_{name} -> {rc}: {self.raw.lbm_last_error_string().decode()}")
+            return rc
+
+        return call
+
+    def device_count(self):
+        return self.raw.lbm_device_count()
+
+
+def _ptr(t):
+    """torch CUDA tensor (float64, contiguous) or int address -> double*"""
+    if t is None:
+        return ct.cast(None, _dp)
+    if isinstance(t, int):
+        return ct.cast(t, _dp)
+    assert t.is_contiguous() and str(t.dtype) == "torch.float64", (t.dtype, t.is_contiguous())
+    return ct.cast(t.data_ptr(), _dp)
+
+
+def _hptr(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def _stream(s):
+    return ct.c_void_p(0 if s is None else int(s))
+
+
+class Solver:
+    """Python face of lbm_solver (single block).  numpy AoS in/out, reference layout."""
+
+    def __init__(self, lib, model, R, C, params, bc=None, stream=None):
+        self.lib, self.R, self.C = lib, R, C
+        self.g = Geom(R, C, 0)
+        self.bc = bc if bc is not None else Bc.periodic()
+        self.params = params
+        self.h = ct.c_void_p()
+        lib.solver_create(ct.byref(self.h), model, ct.byref(self.g), ct.byref(self.bc),
+                          ct.byref(params), _stream(stream))
+
+    def close(self):
+        if self.h:
+            self.lib.solver_destroy(self.h)
+            self.h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_f(self, f):
+        f = np.ascontiguousarray(f, dtype=np.float64)
+        assert f.shape == (self.R, self.C, 9)
+        self.lib.solver_set_f_aos(self.h, _hptr(f))
+
+    def get_f(self):
+        f = np.empty((self.R, self.C, 9))
+        self.lib.solver_get_f_aos(self.h, _hptr(f))
+        return f
+
+    def step(self, n, record_moments=False):
+        self.lib.solver_step(self.h, int(n), int(bool(record_moments)))
+
+    def moments(self):
+        rho = np.empty((self.R, self.C))
+        u = np.empty((self.R, self.C, 2))
+        self.lib.solver_get_moments_aos(self.h, _hptr(rho), _hptr(u))
+        return rho, u
+
+    def sync(self):
+        self.lib.solver_sync(self.h)
+
+    def lattices(self):
+        a, b = _dp(), _dp()
+        self.lib.solver_lattices(self.h, ct.byref(a), ct.byref(b))
+        return ct.cast(a, ct.c_void_p).value, ct.cast(b, ct.c_void_p).value

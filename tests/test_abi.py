@@ -1,0 +1,44 @@
+"""CPU suite: the C-ABI library loads without a GPU and exports every symbol the header
+declares; argument validation works without touching a device."""
+import ctypes as ct
+
+import pytest
+
+import pylbm
+
+
+def test_library_exports_every_declared_symbol():
+    lib = pylbm.load_library()
+    names = pylbm.declared_symbols()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_abi_version_and_device_count():
+    lib = pylbm.Lib()
+    assert lib.raw.lbm_abi_version() == 1
+    assert lib.device_count() >= 0
+
+
+def test_argument_validation_needs_no_gpu():
+    lib = pylbm.Lib()
+    g = pylbm.Geom(0, 16, 0)
+    prm = pylbm.BgkParams(1.2, 0)
+    with pytest.raises(pylbm.LbmError, match="must be positive"):
+        lib.bgk_stream_collide(None, None, ct.byref(g), None, ct.byref(prm), 0, 0, None, None, None)
+    g = pylbm.Geom(16, 16, 0)
+    bad = pylbm.BgkParams(2.5, 0)
+    with pytest.raises(pylbm.LbmError, match="omega"):
+        lib.bgk_stream_collide(None, None, ct.byref(g), None, ct.byref(bad), 0, 16, None, None, None)
+    bc = pylbm.Bc.periodic()
+    bc.row_lo = pylbm.EDGE_HALO
+    with pytest.raises(pylbm.LbmError, match="HALO rows need ghost=1"):
+        lib.bgk_stream_collide(None, None, ct.byref(g), ct.byref(bc), ct.byref(prm), 0, 16, None, None, None)
+    with pytest.raises(pylbm.LbmError, match="NULL"):
+        lib.calc_rho(None, None, 4, 4, None)
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(pylbm.LbmError, match="no CPU fallback"):
+        pylbm.load_library(str(tmp_path / "nope.so"))

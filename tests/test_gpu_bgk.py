@@ -1,0 +1,215 @@
+"""GPU parity tests for the BGK path, all through the C ABI (liblbm_hip.so).
+
+Bars: streaming / layout = bit-exact (pure index work).  Collision arithmetic: the kernels
+are built with -ffp-contract=off and evaluate the reference expressions in the reference
+order, so they are compared BITWISE with the oracle (oracle/lbm_oracle.cpp, itself within a
+few ulp/step of the unmodified reference, see test_oracle_golden.py) and to <= 1e-12
+relative with the golden vectors of the unmodified reference (north star: 1e-6)."""
+import ctypes as ct
+
+import numpy as np
+import pytest
+from conftest import golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import pylbm  # noqa: E402
+from gpu_util import bits_equal, dev, download_aos, ulp_diff, upload_soa  # noqa: E402
+from pylbm import _ptr  # noqa: E402
+from pyoracle import hpt_params  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = pylbm.Lib()
+    assert lib.device_count() >= 1, "no HIP device visible"
+    return lib
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning(lib):
+    yield
+    for k in (b"variant", b"nt", b"grid_cap"):
+        lib.set_tuning(k, 2 if k == b"variant" else 0)
+
+
+def random_state(oracle, R, C, seed):
+    rng = np.random.default_rng(seed)
+    rho = 1 + 0.01 * rng.standard_normal((R, C))
+    u = 0.05 * rng.standard_normal((R, C, 2))
+    return oracle.equilibrium(u, rho) * (1 + 0.01 * rng.standard_normal((R, C, 9)))
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 9), (7, 5, 9), (37, 23, 9), (300, 257, 9), (64, 48, 2), (33, 65, 1)])
+def test_layout_roundtrip_bit_exact(lib, shape):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal(shape)
+    soa = upload_soa(lib, a)
+    R, C, Q = shape
+    # bit-exact node indexing: AoS ((r*C)+c)*Q+q  <->  SoA q*R*C + r*C + c
+    assert bits_equal(soa.cpu().numpy(), np.moveaxis(a, -1, 0))
+    assert bits_equal(download_aos(lib, soa), a)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unfused_operators_vs_oracle_and_golden(lib, oracle, tag):
+    g = golden("solver_units.npz")
+    f, u, rho = g[f"{tag}_f_in"], g[f"{tag}_u_in"], g[f"{tag}_rho_in"]
+    R, C, _ = f.shape
+    fd, ud, rd = upload_soa(lib, f), upload_soa(lib, u), upload_soa(lib, rho)
+    out_s = torch.empty((R, C), dtype=torch.float64, device=dev())
+    out_v = torch.empty((2, R, C), dtype=torch.float64, device=dev())
+    out_f = torch.empty((9, R, C), dtype=torch.float64, device=dev())
+
+    lib.calc_rho(_ptr(out_s), _ptr(fd), R, C, None)
+    got = download_aos(lib, out_s)
+    assert bits_equal(got, oracle.calc_rho(f)) and relerr(got, g[f"{tag}_calc_rho"]) < 1e-15
+    rho_ref = upload_soa(lib, g[f"{tag}_calc_rho"])
+    lib.calc_u(_ptr(out_v), _ptr(fd), _ptr(rho_ref), R, C, None)
+    got = download_aos(lib, out_v)
+    assert bits_equal(got, oracle.calc_u(f, g[f"{tag}_calc_rho"])) and relerr(got, g[f"{tag}_calc_u"]) < 1e-14
+    lib.calc_incomp_u(_ptr(out_v), _ptr(fd), R, C, None)
+    got = download_aos(lib, out_v)
+    assert bits_equal(got, oracle.calc_incomp_u(f)) and relerr(got, g[f"{tag}_calc_incomp_u"]) < 1e-14
+    lib.equilibrium(_ptr(out_f), _ptr(ud), _ptr(rd), R, C, None)
+    got = download_aos(lib, out_f)
+    assert bits_equal(got, oracle.equilibrium(u, rho)) and relerr(got, g[f"{tag}_equilibrium"]) < 1e-15
+    lib.incomp_equilibrium(_ptr(out_f), _ptr(ud), _ptr(rd), R, C, None)
+    got = download_aos(lib, out_f)
+    assert bits_equal(got, oracle.incomp_equilibrium(u, rho))
+    assert relerr(got, g[f"{tag}_incomp_equilibrium"]) < 1e-15
+    feq = upload_soa(lib, g[f"{tag}_equilibrium"])
+    lib.collision(_ptr(out_f), _ptr(fd), _ptr(feq), ct.c_double(1.2), R, C, None)
+    got = download_aos(lib, out_f)
+    assert bits_equal(got, oracle.collision(f, g[f"{tag}_equilibrium"], 1.2))
+    assert relerr(got, g[f"{tag}_collision_w1.2"]) < 1e-15
+    lib.advect(_ptr(out_f), _ptr(fd), R, C, None)
+    assert bits_equal(download_aos(lib, out_f), g[f"{tag}_advect"])  # bit-exact vs the reference
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("inc", [0, 1])
+def test_bgk_periodic_solver_vs_oracle_and_golden(lib, oracle, tag, inc):
+    g = golden("solver_units.npz")
+    f0 = g[f"{tag}_f_in"]
+    R, C, _ = f0.shape
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, pylbm.BgkParams(1.2, inc))
+    sv.set_f(f0)
+    assert bits_equal(sv.get_f(), f0)
+    done = 0
+    for n in (1, 10, 100):
+        sv.step(n - done, record_moments=True)
+        done = n
+        f = sv.get_f()
+        rho, u = sv.moments()
+        fo, rho_o, u_o = oracle.bgk_periodic_steps(f0, 1.2, n, bool(inc))
+        assert bits_equal(f, fo), (n, ulp_diff(f, fo))
+        assert bits_equal(rho, rho_o) and bits_equal(u, u_o)
+        assert relerr(f, g[f"{tag}_bgk{n}_inc{inc}_f"]) < 1e-13
+        assert relerr(rho, g[f"{tag}_bgk{n}_inc{inc}_rho"]) < 1e-13
+        assert relerr(u, g[f"{tag}_bgk{n}_inc{inc}_u"]) < 1e-12
+    sv.close()
+
+
+@pytest.mark.parametrize("R,C", [(40, 64), (33, 512), (16, 1030), (130, 256)])
+def test_interior_kernel_variants_bit_identical(lib, oracle, R, C):
+    """Every tuning variant of the fused pull kernel == generic kernel == oracle, bitwise."""
+    f0 = random_state(oracle, R, C, seed=R * 1000 + C)
+    want, _, _ = oracle.bgk_periodic_steps(f0, 1.6, 7)
+    for variant, nt, cap in [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 3, 0), (1, 3, 0), (2, 1, 64), (2, 2, 7), (1, 0, 5)]:
+        lib.set_tuning(b"variant", variant)
+        lib.set_tuning(b"nt", nt)
+        lib.set_tuning(b"grid_cap", cap)
+        sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, pylbm.BgkParams(1.6, 0))
+        sv.set_f(f0)
+        sv.step(7)
+        got = sv.get_f()
+        sv.close()
+        assert bits_equal(got, want), (variant, nt, cap, ulp_diff(got, want))
+
+
+def hpt_bc(p):
+    bc = pylbm.Bc.periodic()
+    bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+    bc.pressure_rows = 1
+    bc.rho_inlet, bc.rho_outlet = p.rho_inlet, p.rho_outlet
+    return bc
+
+
+def run_hpt_gpu(lib, p, steps):
+    H, W = p.H, p.W
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, H, W, pylbm.BgkParams(p.omega, 1), bc=hpt_bc(p))
+    f0 = np.empty((H, W, 9))
+    f0[...] = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)  # incomp_equilibrium(u=0, rho=1)
+    sv.set_f(f0)
+    return sv
+
+
+def test_poiseuille_main_golden_and_l2(lib, oracle):
+    """config 1 (plumbing): test/horizontal_poiseuille_test.cpp at its own size, 21x21."""
+    g = golden("hpt_21x21.npz")
+    p = hpt_params(21, 21, int(g["T"]))
+    sv = run_hpt_gpu(lib, p, 0)
+    f0 = oracle.hpt_run(hpt_params(21, 21, 0))["f"]
+    assert bits_equal(sv.get_f(), f0)
+    done = 0
+    for k, t in enumerate(g["steps"]):
+        sv.step(int(t) - done, record_moments=True)
+        done = int(t)
+        f = sv.get_f()
+        assert relerr(f, g["fs"][..., k]) < 1e-12, t          # unmodified reference main
+        o = oracle.hpt_run(hpt_params(21, 21, done, check_convergence=0))
+        assert bits_equal(f, o["f"]), (t, ulp_diff(f, o["f"]))  # oracle, bitwise
+    # after T-1 iterations rho/u are what the reference saved in its last snapshot
+    rho, u = sv.moments()
+    k = len(g["steps"]) - 1
+    assert relerr(u[..., 0], g["ux"][..., k]) < 1e-11
+    assert relerr(rho, g["rho"][..., k]) < 1e-13
+    sv.step(1, record_moments=True)  # iteration T: the state the L2 assertion looks at
+    rho, u = sv.moments()
+    W = 21
+    y = np.arange(1, W + 1) - 0.5
+    ua = -4.0 * p.u_max / (W * W) * y * (y - W)
+    err = np.sqrt(((u[1:-1, :, 0] - ua) ** 2).sum(axis=1)) / np.sqrt((ua ** 2).sum())
+    l2 = err.sum() / 21
+    assert l2 <= 1e-11                                         # the reference's own assertion
+    assert abs(l2 - float(g["l2_printed"])) < 5e-14
+    sv.close()
+
+
+def test_poiseuille_config1_256x64_vs_oracle(lib, oracle):
+    """BASELINE config 1: 256x64 BGK Poiseuille; fast interior kernel + edge pass + pressure rows."""
+    p = hpt_params(256, 64, 600, check_convergence=0)
+    sv = run_hpt_gpu(lib, p, 0)
+    sv.step(600, record_moments=True)
+    o = oracle.hpt_run(p)
+    f = sv.get_f()
+    rho, u = sv.moments()
+    assert bits_equal(f, o["f"]), ulp_diff(f, o["f"])
+    assert bits_equal(rho, o["rho"]) and bits_equal(u, o["u"])
+    sv.close()
+
+
+def test_fullsize_box_equals_tiled_small_box(lib, oracle):
+    """BASELINE config 2 size (8192 x 8192): a periodic box whose initial state has period
+    64 x 64 must stay periodic and equal the 64 x 64 periodic box the oracle can run --
+    checks every index computation of the full-size launch, bitwise."""
+    tile = random_state(oracle, 64, 64, seed=5)
+    want, _, _ = oracle.bgk_periodic_steps(tile, 1.2, 6)
+    R = C = 8192
+    t = upload_soa(lib, tile)                         # [9,64,64]
+    big = t.repeat(1, R // 64, C // 64).contiguous()  # [9,8192,8192] SoA
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, pylbm.BgkParams(1.2, 0))
+    lib.solver_set_f_soa_dev(sv.h, _ptr(big))
+    sv.step(6)
+    lib.solver_get_f_soa_dev(sv.h, _ptr(big))
+    torch.cuda.synchronize()
+    blocks = big.view(9, R // 64, 64, C // 64, 64)
+    ref_tile = blocks[:, 0, :, 0, :].contiguous()
+    assert bits_equal(download_aos(lib, ref_tile), want)
+    assert bool((blocks == ref_tile.view(9, 1, 64, 1, 64)).all())  # every tile identical
+    # conservation at full size (exact in exact arithmetic; ~1e-13 relative in f64)
+    mass0 = float(tile.sum()) * (R // 64) * (C // 64)
+    assert abs(float(big.sum()) - mass0) / mass0 < 1e-12
+    sv.close()
