@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--omega", type=float, default=1.2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune", action="append", default=[], help="key=value for lbm_set_tuning")
+    ap.add_argument("--plane-pad", type=int, default=None,
+                    help="doubles of padding between planes (default: lbm_default_plane_pad)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,7 +118,7 @@ def main():
 
     R, C = a.rows, a.cols
     prm = pylbm.BgkParams(a.omega, 0)
-    ring = SlabRing(lib, R, C, rank, world, dev, periodic=True)
+    ring = SlabRing(lib, R, C, rank, world, dev, periodic=True, plane_pad=a.plane_pad)
     f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
     ring.load_precollision(f0, lambda dst, src, geom: lib.bgk_collide(
         _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring.stream_ptr()))
@@ -166,12 +168,13 @@ def main():
             "config": {"workload": f"{R}x{C} D2Q9 BGK periodic box per GPU, Taylor-Green init, "
                                    f"fused collide+stream (pull, two SoA lattices), omega={a.omega}",
                        "rows_per_gpu": R, "cols": C, "global_rows": R * world,
+                       "plane_pad_doubles": ring.plane - (R + 2 * ring.ghost) * C,
                        "parallelism": f"slab{world}" if world > 1 else "single",
                        "halo": "1 row x 3 populations per side over RCCL send/recv" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
-                         "traffic": None, "kernel": "k_stream_collide_v2<BgkModel>",
+                         "traffic": None, "kernel": "k_stream_collide_v3<BgkModel,256,1,nt,nt>",
                          "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": R * C * BYTES_PER_LUP},
             "check": {"total_mass": float(mass), "expected_mass": float(R * C * world)},

@@ -58,6 +58,13 @@ int lbm_event_elapsed_ms(float* ms, void* start, void* stop); /* synchronises on
 /* ---- layout converters (device buffers).  Q = 9 (f), 1 (rho), 2 (u) ---------------- */
 int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Q, lbm_stream_t s);
 int lbm_soa_to_aos(double* aos, const double* soa, int R, int C, int Q, lbm_stream_t s);
+/* same with an explicit SoA plane stride in doubles (0 = dense R*C), see lbm_geom */
+int lbm_aos_to_soa_ex(double* soa, const double* aos, int R, int C, int Q, long long plane_stride,
+                      lbm_stream_t s);
+int lbm_soa_to_aos_ex(double* aos, const double* soa, int R, int C, int Q, long long plane_stride,
+                      lbm_stream_t s);
+/* padding (doubles) the engine recommends between population planes of an R x C lattice */
+long long lbm_default_plane_pad(int R, int C);
 
 /* ---- unfused parity operators: one per solver:: function (src/solver.hpp:11-36) -----
  * SoA planes without ghost rows.  Unlike the reference outputs are written in
@@ -77,6 +84,9 @@ typedef struct lbm_geom {
   int C;     /* columns (reference dim 1, pairs with c_y) */
   int ghost; /* 0: planes are [R][C] and streaming wraps rows periodically inside the block
                 1: planes are [R+2][C]; rows -1 and R are ghost rows owned by the neighbours */
+  long long plane_stride; /* doubles between consecutive population planes; 0 = dense
+                             ((R + 2*ghost) * C).  Padding it off a power of two spreads the 18
+                             concurrent streams of the fused step over the HBM channels. */
 } lbm_geom;
 
 /* What the reference drivers do to the populations a node cannot receive from inside the
@@ -169,10 +179,14 @@ int lbm_solver_get_moments_aos(lbm_solver* sv, double* rho_host, double* u_host)
 int lbm_solver_sync(lbm_solver* sv);
 /* device pointers of the resident lattices (current post-collision, scratch) for callers
  * that drive lbm_*_stream_collide themselves (benchmarks, multi-GPU slabs) */
-int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other);
+int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* geom /* may be NULL */);
 
-/* kernel-variant selector for lbm_bgk_stream_collide's interior path (tuning / tests):
- * 0 = default.  See DESIGN.md "BGK kernel variants". */
+/* Tuning table for lbm_*_stream_collide's interior path (benchmarks / tests; every setting
+ * produces bit-identical results).  Keys: "variant" (0 generic, 1 one node/thread grid-stride,
+ * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0
+ * non-temporal loads, bit 1 non-temporal stores; default 3), "block" (128..1024, default 256),
+ * "rows" (rows per thread 1/2/4, default 1), "grid_cap" (variants 1-2).  value < 0 restores the
+ * default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);
 int lbm_get_tuning(const char* key);
 

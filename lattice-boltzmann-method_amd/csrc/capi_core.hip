@@ -35,7 +35,8 @@ int tuning(const char* key, int dflt) {
 // or tiny (1, 2).
 template <bool TO_SOA>
 __global__ __launch_bounds__(256) void k_layout(double* __restrict__ dst,
-                                                const double* __restrict__ src, long n, int Qn) {
+                                                const double* __restrict__ src, long n, int Qn,
+                                                long ps /* SoA plane stride */) {
   extern __shared__ double tile[];  // [256 * Qn]
   for (long base = (long)blockIdx.x * 256; base < n; base += (long)gridDim.x * 256) {
     const int cnt = (int)((n - base) < 256 ? (n - base) : 256);
@@ -43,10 +44,10 @@ __global__ __launch_bounds__(256) void k_layout(double* __restrict__ dst,
       for (int i = threadIdx.x; i < cnt * Qn; i += 256) tile[i] = src[base * Qn + i];
       __syncthreads();
       if ((int)threadIdx.x < cnt)
-        for (int q = 0; q < Qn; ++q) dst[(long)q * n + base + threadIdx.x] = tile[threadIdx.x * Qn + q];
+        for (int q = 0; q < Qn; ++q) dst[(long)q * ps + base + threadIdx.x] = tile[threadIdx.x * Qn + q];
     } else {
       if ((int)threadIdx.x < cnt)
-        for (int q = 0; q < Qn; ++q) tile[threadIdx.x * Qn + q] = src[(long)q * n + base + threadIdx.x];
+        for (int q = 0; q < Qn; ++q) tile[threadIdx.x * Qn + q] = src[(long)q * ps + base + threadIdx.x];
       __syncthreads();
       for (int i = threadIdx.x; i < cnt * Qn; i += 256) dst[base * Qn + i] = tile[i];
     }
@@ -190,7 +191,8 @@ int lbm_event_elapsed_ms(float* ms, void* start, void* stop) {
 int lbm_set_tuning(const char* key, int value) {
   LBM_REQUIRE(key, "lbm_set_tuning: NULL key");
   std::lock_guard<std::mutex> lk(g_tune_mu);
-  g_tune[key] = value;
+  if (value < 0) g_tune.erase(key);  // back to the built-in default
+  else g_tune[key] = value;
   return LBM_OK;
 }
 int lbm_get_tuning(const char* key) { return key ? tuning(key, 0) : 0; }
@@ -205,23 +207,40 @@ static int check_shape(const char* fn, int R, int C) {
     if (rc_) return rc_;                       \
   } while (0)
 
-int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Qn, lbm_stream_t s) {
+int lbm_aos_to_soa_ex(double* soa, const double* aos, int R, int C, int Qn,
+                      long long plane_stride, lbm_stream_t s) {
   SHAPE_OR_RETURN("lbm_aos_to_soa");
   LBM_REQUIRE(soa && aos && Qn >= 1 && Qn <= 16, "lbm_aos_to_soa: bad pointer or Q=%d", Qn);
   const long n = (long)R * C;
+  LBM_REQUIRE(plane_stride == 0 || plane_stride >= n, "lbm_aos_to_soa: plane_stride too small");
   LBM_KLAUNCH(k_layout<true>, dim3(capped_grid((n + 255) / 256)), dim3(256),
-                     256 * Qn * sizeof(double), as_stream(s), soa, aos, n, Qn);
+              256 * Qn * sizeof(double), as_stream(s), soa, aos, n, Qn,
+              plane_stride ? (long)plane_stride : n);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
-int lbm_soa_to_aos(double* aos, const double* soa, int R, int C, int Qn, lbm_stream_t s) {
+int lbm_soa_to_aos_ex(double* aos, const double* soa, int R, int C, int Qn,
+                      long long plane_stride, lbm_stream_t s) {
   SHAPE_OR_RETURN("lbm_soa_to_aos");
   LBM_REQUIRE(soa && aos && Qn >= 1 && Qn <= 16, "lbm_soa_to_aos: bad pointer or Q=%d", Qn);
   const long n = (long)R * C;
+  LBM_REQUIRE(plane_stride == 0 || plane_stride >= n, "lbm_soa_to_aos: plane_stride too small");
   LBM_KLAUNCH(k_layout<false>, dim3(capped_grid((n + 255) / 256)), dim3(256),
-                     256 * Qn * sizeof(double), as_stream(s), aos, soa, n, Qn);
+              256 * Qn * sizeof(double), as_stream(s), aos, soa, n, Qn,
+              plane_stride ? (long)plane_stride : n);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
+}
+int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Qn, lbm_stream_t s) {
+  return lbm_aos_to_soa_ex(soa, aos, R, C, Qn, 0, s);
+}
+int lbm_soa_to_aos(double* aos, const double* soa, int R, int C, int Qn, lbm_stream_t s) {
+  return lbm_soa_to_aos_ex(aos, soa, R, C, Qn, 0, s);
+}
+long long lbm_default_plane_pad(int R, int C) {
+  // 68 KiB (8704 doubles): off every power-of-two stride, still 4-KiB and 128-B aligned.
+  // Small lattices live in L2 / Infinity Cache and need no padding.
+  return ((long long)R * C >= (1LL << 18)) ? 8704 : 0;
 }
 
 int lbm_calc_rho(double* rho, const double* f, int R, int C, lbm_stream_t s) {
@@ -276,7 +295,7 @@ int lbm_collision(double* fc, const double* f, const double* fe, double omega, i
 int lbm_advect(double* gdst, const double* f, int R, int C, lbm_stream_t s) {
   SHAPE_OR_RETURN("lbm_advect");
   LBM_REQUIRE(gdst && f && gdst != f, "lbm_advect: NULL or aliased pointers");
-  lbm_geom g{R, C, 0};
+  lbm_geom g{R, C, 0, 0};
   return lbm_stream(gdst, f, &g, nullptr, s);
 }
 

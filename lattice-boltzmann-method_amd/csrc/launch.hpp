@@ -10,6 +10,8 @@ inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc)
   LBM_REQUIRE(g, "%s: NULL geometry", fn);
   LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
   LBM_REQUIRE(g->ghost == 0 || g->ghost == 1, "%s: ghost=%d must be 0 or 1", fn, g->ghost);
+  LBM_REQUIRE(g->plane_stride == 0 || g->plane_stride >= (long long)(g->R + 2 * g->ghost) * g->C,
+              "%s: plane_stride=%lld smaller than a plane", fn, g->plane_stride);
   if (bc) {
     auto row_ok = [](int m) {
       return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || m == LBM_EDGE_BOUNCE_BACK ||
@@ -49,7 +51,7 @@ int launch_stream_collide(const char* fn, double* pn, const double* po, const lb
   const Bc bc = make_bc(lbc);
   const bool mom = rho != nullptr;
   const int nrows = row_end - row_begin;
-  const int variant = tuning("variant", 2);
+  const int variant = tuning("variant", 3);
   const bool fast = (g.C % 2 == 0) && g.C >= 64 && variant != 0;
 
   if (!fast) {  // generic path: boundary gather on every node
@@ -61,7 +63,7 @@ int launch_stream_collide(const char* fn, double* pn, const double* po, const lb
     return LBM_OK;
   }
 
-  const int nt = tuning("nt", 0);  // bit 0: non-temporal loads, bit 1: non-temporal stores
+  const int nt = tuning("nt", 3);  // bit 0: non-temporal loads, bit 1: non-temporal stores
   const int cap = tuning("grid_cap", 0);
 #define LBM_LAUNCH_VARIANT(KERNEL, NODES_PER_THREAD)                                            \
   do {                                                                                          \
@@ -76,7 +78,30 @@ int launch_stream_collide(const char* fn, double* pn, const double* po, const lb
       default: LBM_KLAUNCH((KERNEL<Model, false, false, true>), dim3(grid), dim3(256), 0, st, pn, po, g, m, row_begin, row_end, tiles, rho, u); break; \
     }                                                                                           \
   } while (0)
-  if (variant == 1) LBM_LAUNCH_VARIANT(k_stream_collide_v1, 1);
+  if (variant == 3 && !mom) {
+    const int block = tuning("block", 256), rows = tuning("rows", 1);
+    const int swz = tuning("xcd_swizzle", 0);  // measured slower at 8192^2
+#define LBM_V3(B, RW)                                                                              \
+  if (block == B && rows == RW) {                                                                  \
+    const int tiles_x = (g.C + B - 1) / B;                                                         \
+    const long items_l = (long)tiles_x * ((nrows + RW - 1) / RW);                                  \
+    LBM_REQUIRE(items_l < (1L << 30), "%s: lattice too large for one launch", fn);                 \
+    const int n_items = (int)items_l;                                                              \
+    const dim3 grid(swz ? ((n_items + 7) / 8) * 8 : n_items);                                      \
+    switch (nt & 3) {                                                                              \
+      case 0: LBM_KLAUNCH((k_stream_collide_v3<Model, B, RW, false, false>), grid, dim3(B), 0, st, pn, po, g, m, row_begin, row_end, tiles_x, n_items, swz); break; \
+      case 1: LBM_KLAUNCH((k_stream_collide_v3<Model, B, RW, true, false>), grid, dim3(B), 0, st, pn, po, g, m, row_begin, row_end, tiles_x, n_items, swz); break;  \
+      case 2: LBM_KLAUNCH((k_stream_collide_v3<Model, B, RW, false, true>), grid, dim3(B), 0, st, pn, po, g, m, row_begin, row_end, tiles_x, n_items, swz); break;  \
+      default: LBM_KLAUNCH((k_stream_collide_v3<Model, B, RW, true, true>), grid, dim3(B), 0, st, pn, po, g, m, row_begin, row_end, tiles_x, n_items, swz); break;  \
+    }                                                                                              \
+  } else
+    LBM_V3(128, 1) LBM_V3(256, 1) LBM_V3(512, 1) LBM_V3(1024, 1) LBM_V3(128, 2) LBM_V3(256, 2)
+    LBM_V3(512, 2) LBM_V3(256, 4) LBM_V3(128, 4) {
+      set_error("%s: no v3 instantiation for block=%d rows=%d", fn, block, rows);
+      return LBM_ERR_INVALID;
+    }
+#undef LBM_V3
+  } else if (variant == 1) LBM_LAUNCH_VARIANT(k_stream_collide_v1, 1);
   else LBM_LAUNCH_VARIANT(k_stream_collide_v2, 2);
 #undef LBM_LAUNCH_VARIANT
   LBM_CHECK_LAUNCH();

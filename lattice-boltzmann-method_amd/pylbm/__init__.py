@@ -23,7 +23,11 @@ _dp = ct.POINTER(ct.c_double)
 
 
 class Geom(ct.Structure):
-    _fields_ = [("R", ct.c_int), ("C", ct.c_int), ("ghost", ct.c_int)]
+    _fields_ = [("R", ct.c_int), ("C", ct.c_int), ("ghost", ct.c_int),
+                ("plane_stride", ct.c_longlong)]
+
+    def __init__(self, R=0, C=0, ghost=0, plane_stride=0):
+        super().__init__(R, C, ghost, plane_stride)
 
 
 class Bc(ct.Structure):
@@ -72,6 +76,7 @@ def load_library(path=LIB_PATH):
             "or `make -C lattice-boltzmann-method_amd/csrc` (no CPU fallback exists)")
     lib = ct.CDLL(path)
     lib.lbm_last_error_string.restype = ct.c_char_p
+    lib.lbm_default_plane_pad.restype = ct.c_longlong
     return lib
 
 
@@ -95,6 +100,13 @@ class Lib:
     def device_count(self):
         return self.raw.lbm_device_count()
 
+    def default_plane_pad(self, R, C):
+        return int(self.raw.lbm_default_plane_pad(R, C))
+
+    def reset_tuning(self):
+        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle"):
+            self.set_tuning(k, -1)
+
 
 def _ptr(t):
     """torch CUDA tensor (float64, contiguous) or int address -> double*"""
@@ -102,7 +114,8 @@ def _ptr(t):
         return ct.cast(None, _dp)
     if isinstance(t, int):
         return ct.cast(t, _dp)
-    assert t.is_contiguous() and str(t.dtype) == "torch.float64", (t.dtype, t.is_contiguous())
+    # strided lattice views (padded planes) are fine: the geometry carries the plane stride
+    assert t.stride(-1) == 1 and str(t.dtype) == "torch.float64", (t.dtype, t.stride())
     return ct.cast(t.data_ptr(), _dp)
 
 
@@ -161,6 +174,6 @@ class Solver:
         self.lib.solver_sync(self.h)
 
     def lattices(self):
-        a, b = _dp(), _dp()
-        self.lib.solver_lattices(self.h, ct.byref(a), ct.byref(b))
-        return ct.cast(a, ct.c_void_p).value, ct.cast(b, ct.c_void_p).value
+        a, b, g = _dp(), _dp(), Geom()
+        self.lib.solver_lattices(self.h, ct.byref(a), ct.byref(b), ct.byref(g))
+        return ct.cast(a, ct.c_void_p).value, ct.cast(b, ct.c_void_p).value, g

@@ -27,11 +27,16 @@ TO_PREV = (3, 6, 7)  # c_x = -1: leave through the first owned row
 
 
 class SlabRing:
-    def __init__(self, lib, R, C, rank, world, dev, periodic=True, bc=None):
+    def __init__(self, lib, R, C, rank, world, dev, periodic=True, bc=None, plane_pad=None):
         self.lib, self.R, self.C, self.rank, self.world, self.dev = lib, R, C, rank, world, dev
         self.periodic = periodic
         self.ghost = 0 if world == 1 else 1
-        self.geom = Geom(R, C, self.ghost)
+        rows = R + 2 * self.ghost
+        # plane stride in doubles; a pad keeps the 9 planes off a common power-of-two stride
+        if plane_pad is None:
+            plane_pad = lib.default_plane_pad(rows, C) if lib is not None else 0
+        self.plane = rows * C + plane_pad
+        self.geom = Geom(R, C, self.ghost, self.plane if plane_pad else 0)
         self.bc = bc if bc is not None else Bc.periodic()
         if world > 1:
             first, last = rank == 0, rank == world - 1
@@ -39,8 +44,8 @@ class SlabRing:
                 self.bc.row_lo = EDGE_HALO
             if periodic or not last:
                 self.bc.row_hi = EDGE_HALO
-        rows = R + 2 * self.ghost
-        self.lat = [torch.zeros((9, rows, C), dtype=torch.float64, device=dev) for _ in range(2)]
+        self.buf = [torch.zeros(9 * self.plane, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.lat = [b.as_strided((9, rows, C), (self.plane, C, 1)) for b in self.buf]
         self.cur = 0
         self.next_rank = (rank + 1) % world if (periodic or rank < world - 1) else None
         self.prev_rank = (rank - 1) % world if (periodic or rank > 0) else None

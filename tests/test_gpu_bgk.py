@@ -30,8 +30,7 @@ def lib():
 @pytest.fixture(autouse=True)
 def _reset_tuning(lib):
     yield
-    for k in (b"variant", b"nt", b"grid_cap"):
-        lib.set_tuning(k, 2 if k == b"variant" else 0)
+    lib.reset_tuning()
 
 
 def random_state(oracle, R, C, seed):
@@ -117,16 +116,23 @@ def test_interior_kernel_variants_bit_identical(lib, oracle, R, C):
     """Every tuning variant of the fused pull kernel == generic kernel == oracle, bitwise."""
     f0 = random_state(oracle, R, C, seed=R * 1000 + C)
     want, _, _ = oracle.bgk_periodic_steps(f0, 1.6, 7)
-    for variant, nt, cap in [(0, 0, 0), (1, 0, 0), (2, 0, 0), (2, 3, 0), (1, 3, 0), (2, 1, 64), (2, 2, 7), (1, 0, 5)]:
+    combos = [(0, 0, 0, 256, 1), (1, 0, 0, 256, 1), (2, 0, 0, 256, 1), (2, 3, 0, 256, 1),
+              (1, 3, 0, 256, 1), (2, 1, 64, 256, 1), (2, 2, 7, 256, 1), (1, 0, 5, 256, 1),
+              (3, 3, 0, 256, 1), (3, 0, 0, 128, 1), (3, 1, 0, 512, 2), (3, 2, 0, 1024, 1),
+              (3, 3, 0, 256, 4), (3, 3, 0, 128, 2)]
+    for variant, nt, cap, block, rows in combos:
         lib.set_tuning(b"variant", variant)
         lib.set_tuning(b"nt", nt)
         lib.set_tuning(b"grid_cap", cap)
+        lib.set_tuning(b"block", block)
+        lib.set_tuning(b"rows", rows)
+        lib.set_tuning(b"xcd_swizzle", (block // 128 + rows) % 2)
         sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, pylbm.BgkParams(1.6, 0))
         sv.set_f(f0)
         sv.step(7)
         got = sv.get_f()
         sv.close()
-        assert bits_equal(got, want), (variant, nt, cap, ulp_diff(got, want))
+        assert bits_equal(got, want), (variant, nt, cap, block, rows, ulp_diff(got, want))
 
 
 def hpt_bc(p):
