@@ -219,3 +219,52 @@ def test_fullsize_box_equals_tiled_small_box(lib, oracle):
     mass0 = float(tile.sum()) * (R // 64) * (C // 64)
     assert abs(float(big.sum()) - mass0) / mass0 < 1e-12
     sv.close()
+
+
+def test_two_slabs_on_one_gpu_equal_single_block(lib, oracle):
+    """The ghost-row (slab) code path of the fused kernel: 2 slabs emulated on one GPU, halo =
+    3 populations per side copied by hand (what SlabRing sends over RCCL), boundary rows and
+    interior rows launched separately as in the overlap schedule.  Must equal the single
+    periodic block bitwise (the contract of test/decompose_domain.cpp:181-187)."""
+    from pylbm.slab import TO_NEXT, TO_PREV
+    Rg, C, n = 96, 256, 6
+    R = Rg // 2
+    f0 = random_state(oracle, Rg, C, seed=77)
+    want, _, _ = oracle.bgk_periodic_steps(f0, 1.4, n)
+    prm = pylbm.BgkParams(1.4, 0)
+    flat = pylbm.Geom(Rg, C, 0)
+    p0 = torch.empty((9, Rg, C), dtype=torch.float64, device=dev())
+    f0d = upload_soa(lib, f0)
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(flat), None, ct.byref(prm), None, None, None)
+    torch.cuda.synchronize()
+    geom = pylbm.Geom(R, C, 1)
+    bc = pylbm.Bc.periodic()
+    bc.row_lo = bc.row_hi = pylbm.EDGE_HALO
+    lat = [[torch.zeros((9, R + 2, C), dtype=torch.float64, device=dev()) for _ in range(2)] for _ in range(2)]
+
+    def halo(cur):
+        for s in range(2):
+            nxt = prv = 1 - s  # ring of two
+            for q in TO_NEXT:
+                lat[nxt][cur][q, 0] = lat[s][cur][q, R]
+            for q in TO_PREV:
+                lat[prv][cur][q, R + 1] = lat[s][cur][q, 1]
+
+    for s in range(2):
+        lat[s][0][:, 1:R + 1] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    cur = 0
+    for _ in range(n - 1):
+        for s in range(2):
+            src, dst = lat[s][cur], lat[s][cur ^ 1]
+            for r0, r1 in ((0, 1), (R - 1, R), (1, R - 1)):
+                lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc),
+                                       ct.byref(prm), r0, r1, None, None, None)
+        torch.cuda.synchronize()
+        cur ^= 1
+        halo(cur)
+    p = torch.cat([lat[0][cur][:, 1:R + 1], lat[1][cur][:, 1:R + 1]], dim=1).contiguous()
+    out = torch.empty_like(p)
+    lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
+    got = download_aos(lib, out)
+    assert bits_equal(got, want), ulp_diff(got, want)

@@ -1,0 +1,101 @@
+"""CPU suite: the N>1 path (pylbm.slab.SlabRing = halo exchange + boundary/interior split)
+under torch.distributed `gloo`, world_size 2 and 3, one process per slab.  Compute is
+injected (a numpy restatement of the fused pull step on the ghost-row layout); the result of
+N slabs must equal the oracle's single global box -- the contract test/decompose_domain.cpp
+demonstrates for two blocks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "lattice-boltzmann-method_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+W9 = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+CX = np.array([0, 1, 0, -1, 0, 1, -1, -1, 1])
+CY = np.array([0, 0, 1, 0, -1, 1, 1, -1, -1])
+OMEGA = 1.3
+
+
+def np_collide(f):
+    """BGK compressible collide on SoA [9, n, C] (solver.cpp:23-74)."""
+    rho = f.sum(axis=0)
+    ux = np.tensordot(CX, f, axes=1) / rho
+    uy = np.tensordot(CY, f, axes=1) / rho
+    uu = ux * ux + uy * uy
+    out = np.empty_like(f)
+    for q in range(9):
+        cu = ux * CX[q] + uy * CY[q]
+        feq = rho * (1.0 + 3.0 * cu + 4.5 * cu * cu - 1.5 * uu) * W9[q]
+        out[q] = (1.0 - OMEGA) * f[q] + OMEGA * feq
+    return out
+
+
+def np_step_rows(dst, src, geom, bc, r0, r1):
+    """dst rows [r0, r1) = collide(stream(src)) on the [9, R+2, C] ghost layout (pull)."""
+    s, d = src.numpy(), dst.numpy()
+    g = geom.ghost
+    assert g == 1
+    f = np.empty((9, r1 - r0, geom.C))
+    for q in range(9):
+        rows = s[q, g + r0 - CX[q]: g + r1 - CX[q], :]
+        f[q] = np.roll(rows, CY[q], axis=1)
+    d[:, g + r0: g + r1, :] = np_collide(f)
+
+
+def worker(rank, world, port, R, C, steps, f0_path, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pylbm.slab import SlabRing
+    f0 = np.load(f0_path)  # global AoS [R*world, C, 9]
+    mine = np.ascontiguousarray(np.moveaxis(f0[rank * R:(rank + 1) * R], -1, 0))  # SoA [9,R,C]
+    ring = SlabRing(None, R, C, rank, world, torch.device("cpu"), periodic=True, plane_pad=7)
+    ring.load_precollision(torch.from_numpy(mine), lambda dst, src, geom: dst.copy_(
+        torch.from_numpy(np_collide(src.numpy()))))
+    for _ in range(steps - 1):  # n driver iterations = 1 collide + (n-1) fused steps
+        ring.step(np_step_rows)
+    parts = [torch.empty_like(ring.owned().contiguous()) for _ in range(world)]
+    dist.all_gather(parts, ring.owned().contiguous())
+    if rank == 0:
+        np.save(out_path, torch.cat(parts, dim=1).numpy())  # global P, SoA [9, R*world, C]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slab_ring_equals_single_box(world, tmp_path, oracle):
+    R, C, steps = 6, 16, 9
+    rng = np.random.default_rng(world)
+    rho = 1 + 0.02 * rng.standard_normal((R * world, C))
+    u = 0.05 * rng.standard_normal((R * world, C, 2))
+    f0 = oracle.equilibrium(u, rho) * (1 + 0.01 * rng.standard_normal((R * world, C, 9)))
+    f0_path, out_path = str(tmp_path / "f0.npy"), str(tmp_path / "p.npy")
+    np.save(f0_path, f0)
+    port = 29500 + (os.getpid() % 2000) + world
+    mp.start_processes(worker, args=(world, port, R, C, steps, f0_path, out_path), nprocs=world,
+                       join=True, start_method="spawn")
+    p_global = np.moveaxis(np.load(out_path), 0, -1)          # AoS post-collision populations
+    got = oracle.advect(np.ascontiguousarray(p_global))       # f_adve after `steps` iterations
+    want, _, _ = oracle.bgk_periodic_steps(f0, OMEGA, steps)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13
+
+
+def test_ring_neighbours_and_edge_modes():
+    """Non-periodic chain: end slabs keep their physical row BC, interior rows are HALO."""
+    from pylbm import EDGE_BOUNCE_BACK, EDGE_HALO, Bc
+    from pylbm.slab import SlabRing
+    for rank in range(4):
+        bc = Bc.periodic()
+        bc.row_lo = bc.row_hi = EDGE_BOUNCE_BACK
+        ring = SlabRing(None, 4, 8, rank, 4, torch.device("cpu"), periodic=False, bc=bc, plane_pad=0)
+        assert ring.prev_rank == (rank - 1 if rank > 0 else None)
+        assert ring.next_rank == (rank + 1 if rank < 3 else None)
+        assert ring.bc.row_lo == (EDGE_BOUNCE_BACK if rank == 0 else EDGE_HALO)
+        assert ring.bc.row_hi == (EDGE_BOUNCE_BACK if rank == 3 else EDGE_HALO)
+        assert ring.lat[0].shape == (9, 6, 8) and ring.geom.ghost == 1
