@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=value for lbm_set_tuning")
     ap.add_argument("--plane-pad", type=int, default=None,
                     help="doubles of padding between planes (default: lbm_default_plane_pad)")
+    ap.add_argument("--force-halo", action="store_true",
+                    help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,8 +108,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback on the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.force_halo
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     lib = pylbm.Lib()
@@ -118,7 +122,8 @@ def main():
 
     R, C = a.rows, a.cols
     prm = pylbm.BgkParams(a.omega, 0)
-    ring = SlabRing(lib, R, C, rank, world, dev, periodic=True, plane_pad=a.plane_pad)
+    ring = SlabRing(lib, R, C, rank, world, dev, periodic=True, plane_pad=a.plane_pad,
+                    force_ghost=a.force_halo)
     f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
     ring.load_precollision(f0, lambda dst, src, geom: lib.bgk_collide(
         _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring.stream_ptr()))
@@ -128,6 +133,7 @@ def main():
         lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
                                r0, r1, None, None, ring.stream_ptr())
 
+    ring.autotune(step_rows)          # picks the overlap schedule (no-op without ghost rows)
     for _ in range(a.warmup):
         ring.step(step_rows)
     torch.cuda.synchronize()
@@ -170,7 +176,9 @@ def main():
                        "rows_per_gpu": R, "cols": C, "global_rows": R * world,
                        "plane_pad_doubles": ring.plane - (R + 2 * ring.ghost) * C,
                        "parallelism": f"slab{world}" if world > 1 else "single",
-                       "halo": "1 row x 3 populations per side over RCCL send/recv" if world > 1 else "none"},
+                       "halo": "1 row x 3 populations per side over RCCL send/recv" if ring.ghost else "none",
+                       "overlap_schedule": ring.schedule if ring.ghost else None,
+                       "schedule_ms": getattr(ring, "autotune_ms", None)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
@@ -182,7 +190,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

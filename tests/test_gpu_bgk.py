@@ -268,3 +268,40 @@ def test_two_slabs_on_one_gpu_equal_single_block(lib, oracle):
     lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
     got = download_aos(lib, out)
     assert bits_equal(got, want), ulp_diff(got, want)
+
+
+def test_slab_ring_rccl_self_exchange(lib, oracle):
+    """SlabRing's real transport on the GPU box: torch.distributed backend nccl (= RCCL) with
+    world_size 1 and forced ghost rows, so every halo row is an RCCL send/recv to self posted
+    through the same batch_isend_irecv call the 8-GPU run uses.  Result == single block."""
+    import torch.distributed as dist
+    from pylbm.slab import SlabRing
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    d = dev()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=d)
+    try:
+        R, C, n = 64, 256, 8
+        f0 = random_state(oracle, R, C, seed=31)
+        want, _, _ = oracle.bgk_periodic_steps(f0, 1.1, n)
+        prm = pylbm.BgkParams(1.1, 0)
+        ring = SlabRing(lib, R, C, 0, 1, d, periodic=True, force_ghost=True)
+        assert ring.ghost == 1 and ring.next_rank == 0 and ring.prev_rank == 0
+        f0d = upload_soa(lib, f0)
+        ring.load_precollision(f0d, lambda dst, src, geom: lib.bgk_collide(
+            _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring.stream_ptr()))
+
+        def step_rows(dst, src, geom, bc, r0, r1):
+            lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
+                                   r0, r1, None, None, ring.stream_ptr())
+        for _ in range(n - 1):
+            ring.step(step_rows)
+        torch.cuda.synchronize()
+        p = ring.owned().contiguous()
+        out = torch.empty_like(p)
+        lib.stream(_ptr(out), _ptr(p), ct.byref(pylbm.Geom(R, C, 0)), None, None)
+        got = download_aos(lib, out)
+        assert bits_equal(got, want), ulp_diff(got, want)
+    finally:
+        dist.destroy_process_group()
