@@ -154,6 +154,54 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            const lbm_bc* bc, const lbm_kbc_params* prm, int row_begin,
                            int row_end, double* rho, double* u, lbm_stream_t s);
 
+/* ---- colour-gradient two-phase MRT (test/mrtcg_rayleigh_taylor.cpp; BASELINE config 4) ----
+ * Two passes per step over post-collision populations of both colours:
+ * lbm_cg_stream_moments (stream -> rho_r, rho_b, u) then lbm_cg_stream_collide (5x5 stencils
+ * from an LDS tile, MRT + perturbation + recolouring + gravity source).  496 B/LUP + halo. */
+typedef struct lbm_cg_colour {
+  double rho_0; /* [red]/[blue] initial_density            (src/colour.cpp:12) */
+  double alpha; /* alpha                                    (:13) */
+  double nu;    /* kinematic_viscosity                      (:15) */
+  double beta;  /* interface_thickness_control              (:17) */
+} lbm_cg_colour;
+typedef struct lbm_cg_params {
+  lbm_cg_colour red, blue;
+  double sigma;   /* [general] sigma              (mrtcg_rayleigh_taylor.cpp:360) */
+  double gravity; /* [general] gravity_magnitude  (:361), Fg = (gravity, 0) along +r (:403) */
+  double delta;   /* interface half-width of the s_nu blend; the driver hard-codes 0.1 (:375) */
+} lbm_cg_params;
+/* the driver's boundary set (:495-533): bounce-back rows, same-row column copy */
+void lbm_cg_default_bc(lbm_bc* bc);
+/* eval_equilibrium (:233-247): f[9][R][C] (plane stride as given) from rho_k[R][C], u[2][R][C] */
+int lbm_cg_equilibrium(double* f, const double* rho_k, const double* u, const lbm_cg_colour* k,
+                       int R, int C, long long plane_stride, lbm_stream_t s);
+/* one loop body :431-464 on the GIVEN macroscopic fields and un-streamed populations (the
+ * driver's first iteration: u = 0, rho_k = init); writes post-collision col_f of both colours */
+int lbm_cg_collide(double* p_r, double* p_b, const double* f_r, const double* f_b,
+                   const double* rho_r, const double* rho_b, const double* u, const lbm_geom* g,
+                   const lbm_bc* bc, const lbm_cg_params* prm, double* psi /* may be NULL */,
+                   double* s_nu /* may be NULL */, lbm_stream_t s);
+/* pass A: :466-477 fused -- advect + BCs of both colours, rho_k, u incl. the Fg/(2 rho) shift */
+int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double* p_r,
+                          const double* p_b, const lbm_geom* g, const lbm_bc* bc,
+                          const lbm_cg_params* prm, lbm_stream_t s);
+/* pass B: :431-464 on the streamed populations */
+int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                          const double* rho_r, const double* rho_b, const double* u,
+                          const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm,
+                          double* psi, double* s_nu, lbm_stream_t s);
+/* driver loop context (single block); host arrays in the reference's shapes */
+typedef struct lbm_cg_solver lbm_cg_solver;
+int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* bc /* NULL = default */,
+                         const lbm_cg_params* prm, lbm_stream_t s);
+int lbm_cg_solver_destroy(lbm_cg_solver* sv);
+int lbm_cg_solver_set_state(lbm_cg_solver* sv, const double* f_r, const double* f_b,
+                            const double* rho_r, const double* rho_b, const double* u);
+int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps);
+int lbm_cg_solver_get_state(lbm_cg_solver* sv, double* f_r, double* f_b, double* rho_r,
+                            double* rho_b, double* u, double* psi, double* s_nu);
+int lbm_cg_solver_sync(lbm_cg_solver* sv);
+
 /* ---- solver context: one block, two lattices, the driver loop ----------------------------
  * Replaces the hand-written time loops of the reference drivers (e.g.
  * horizontal_poiseuille_test.cpp:100-153).  The context keeps POST-collision populations

@@ -1,0 +1,272 @@
+// C ABI, part 5: colour-gradient two-phase MRT step (test/mrtcg_rayleigh_taylor.cpp).
+#include <new>
+
+#include "cg.hpp"
+#include "launch.hpp"
+
+namespace lbm {
+
+__global__ __launch_bounds__(256) void k_cg_equilibrium(double* __restrict__ f,
+                                                        const double* __restrict__ rho_k,
+                                                        const double* __restrict__ u, long n,
+                                                        long plane, CgColour k) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    double e[Q];
+    cg_feq(e, rho_k[i], k, u[i], u[n + i]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) f[q * plane + i] = e[q];
+  }
+}
+
+static int check_cg(const char* fn, const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* p) {
+  int rc = validate_geom_bc(fn, g, bc);
+  if (rc) return rc;
+  LBM_REQUIRE(p, "%s: NULL params", fn);
+  LBM_REQUIRE(g->ghost == 0, "%s: single block only in this version (ghost=0)", fn);
+  LBM_REQUIRE(p->red.rho_0 > 0 && p->blue.rho_0 > 0 && p->delta > 0, "%s: bad colour parameters", fn);
+  LBM_REQUIRE(p->red.alpha < 1.0 && p->blue.alpha < 1.0, "%s: alpha must be < 1", fn);
+  return LBM_OK;
+}
+
+static int launch_cg_collide(bool from_post, double* pn_r, double* pn_b, const double* in_r,
+                             const double* in_b, const double* rho_r, const double* rho_b,
+                             const double* u, const lbm_geom* lg, const lbm_bc* lbc,
+                             const lbm_cg_params* prm, double* psi, double* snu, hipStream_t st) {
+  const Geom g = make_geom(*lg);
+  const Bc bc = make_bc(lbc);
+  const CgConsts cc = make_cg_consts(*prm);
+  const int tiles = ((g.R + CG_TR - 1) / CG_TR) * ((g.C + CG_TC - 1) / CG_TC);
+  const bool fields = psi != nullptr;
+  if (from_post) {
+    if (fields) LBM_KLAUNCH((k_cg_collide<true, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
+    else LBM_KLAUNCH((k_cg_collide<true, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
+  } else {
+    if (fields) LBM_KLAUNCH((k_cg_collide<false, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
+    else LBM_KLAUNCH((k_cg_collide<false, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
+  }
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+}  // namespace lbm
+
+using namespace lbm;
+
+extern "C" {
+
+void lbm_cg_default_bc(lbm_bc* bc) {
+  // apply_boundary_conditions, mrtcg_rayleigh_taylor.cpp:495-533
+  if (!bc) return;
+  *bc = lbm_bc{LBM_EDGE_BOUNCE_BACK, LBM_EDGE_BOUNCE_BACK, LBM_EDGE_WRAP_NOSHIFT,
+               LBM_EDGE_WRAP_NOSHIFT, 0, 1.0, 1.0, 0.0, 0.0};
+}
+
+int lbm_cg_equilibrium(double* f, const double* rho_k, const double* u, const lbm_cg_colour* k,
+                       int R, int C, long long plane_stride, lbm_stream_t s) {
+  LBM_REQUIRE(f && rho_k && u && k && R > 0 && C > 0, "lbm_cg_equilibrium: bad argument");
+  lbm_cg_params p{*k, *k, 0.0, 0.0, 0.1};
+  const CgConsts cc = make_cg_consts(p);
+  const long n = (long)R * C;
+  LBM_REQUIRE(plane_stride == 0 || plane_stride >= n, "lbm_cg_equilibrium: plane_stride too small");
+  LBM_KLAUNCH(k_cg_equilibrium, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), f,
+              rho_k, u, n, plane_stride ? (long)plane_stride : n, cc.k[0]);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_cg_collide(double* p_r, double* p_b, const double* f_r, const double* f_b,
+                   const double* rho_r, const double* rho_b, const double* u, const lbm_geom* g,
+                   const lbm_bc* bc, const lbm_cg_params* prm, double* psi, double* snu,
+                   lbm_stream_t s) {
+  int rc = check_cg("lbm_cg_collide", g, bc, prm);
+  if (rc) return rc;
+  LBM_REQUIRE(p_r && p_b && f_r && f_b && rho_r && rho_b && u, "lbm_cg_collide: NULL pointer");
+  LBM_REQUIRE((psi == nullptr) == (snu == nullptr), "lbm_cg_collide: psi and s_nu go together");
+  return launch_cg_collide(false, p_r, p_b, f_r, f_b, rho_r, rho_b, u, g, bc, prm, psi, snu, as_stream(s));
+}
+
+int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double* p_r,
+                          const double* p_b, const lbm_geom* g, const lbm_bc* bc,
+                          const lbm_cg_params* prm, lbm_stream_t s) {
+  int rc = check_cg("lbm_cg_stream_moments", g, bc, prm);
+  if (rc) return rc;
+  LBM_REQUIRE(rho_r && rho_b && u && p_r && p_b, "lbm_cg_stream_moments: NULL pointer");
+  const Geom gg = make_geom(*g);
+  const long n = (long)gg.R * gg.C;
+  LBM_KLAUNCH(k_cg_stream_moments, dim3(capped_grid((n + 255) / 256, 8192)), dim3(256), 0, as_stream(s),
+              rho_r, rho_b, u, p_r, p_b, gg, make_bc(bc), prm->gravity);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                          const double* rho_r, const double* rho_b, const double* u,
+                          const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm,
+                          double* psi, double* snu, lbm_stream_t s) {
+  int rc = check_cg("lbm_cg_stream_collide", g, bc, prm);
+  if (rc) return rc;
+  LBM_REQUIRE(pn_r && pn_b && p_r && p_b && rho_r && rho_b && u, "lbm_cg_stream_collide: NULL pointer");
+  LBM_REQUIRE(pn_r != p_r && pn_b != p_b, "lbm_cg_stream_collide: aliased lattices");
+  LBM_REQUIRE((psi == nullptr) == (snu == nullptr), "lbm_cg_stream_collide: psi and s_nu go together");
+  return launch_cg_collide(true, pn_r, pn_b, p_r, p_b, rho_r, rho_b, u, g, bc, prm, psi, snu, as_stream(s));
+}
+
+}  // extern "C"
+
+// ---- solver context for the two-phase driver loop -----------------------------------------------
+struct lbm_cg_solver {
+  lbm_geom g;
+  lbm_bc bc;
+  lbm_cg_params prm;
+  hipStream_t st;
+  double* lat[2][2];  // [buffer][colour]
+  double *rho_r, *rho_b, *u, *psi, *snu, *stage;
+  int cur;
+  bool post;
+  long steps;
+};
+
+extern "C" {
+
+int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* bc,
+                         const lbm_cg_params* prm, lbm_stream_t s) {
+  LBM_REQUIRE(out, "lbm_cg_solver_create: NULL out pointer");
+  lbm_bc dflt;
+  lbm_cg_default_bc(&dflt);
+  int rc = check_cg("lbm_cg_solver_create", g, bc ? bc : &dflt, prm);
+  if (rc) return rc;
+  lbm_cg_solver* sv = new (std::nothrow) lbm_cg_solver();
+  LBM_REQUIRE(sv, "lbm_cg_solver_create: out of host memory");
+  sv->g = *g;
+  sv->bc = bc ? *bc : dflt;
+  sv->prm = *prm;
+  sv->st = as_stream(s);
+  sv->cur = 0;
+  sv->post = false;
+  sv->steps = 0;
+  const size_t n = (size_t)g->R * g->C;
+  sv->g.plane_stride = (long long)n + lbm_default_plane_pad(g->R, g->C);
+  const size_t lat_bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
+  double** all[] = {&sv->lat[0][0], &sv->lat[0][1], &sv->lat[1][0], &sv->lat[1][1], &sv->rho_r,
+                    &sv->rho_b, &sv->u, &sv->psi, &sv->snu, &sv->stage};
+  const size_t bytes[] = {lat_bytes, lat_bytes, lat_bytes, lat_bytes, n * 8, n * 8, n * 16, n * 8, n * 8, n * 72};
+  for (auto p : all) *p = nullptr;
+  for (int i = 0; i < 10; ++i) {
+    hipError_t e = hipMalloc(all[i], bytes[i]);
+    if (e != hipSuccess) {
+      set_error("lbm_cg_solver_create: hipMalloc failed: %s", hipGetErrorString(e));
+      lbm_cg_solver_destroy(sv);
+      return LBM_ERR_HIP;
+    }
+  }
+  LBM_CHECK_HIP(hipMemsetAsync(sv->psi, 0, n * 8, sv->st));  // phase_field / s_nu start as zeros (:380,:382)
+  LBM_CHECK_HIP(hipMemsetAsync(sv->snu, 0, n * 8, sv->st));
+  *out = sv;
+  return LBM_OK;
+}
+
+int lbm_cg_solver_destroy(lbm_cg_solver* sv) {
+  if (!sv) return LBM_OK;
+  for (double* p : {sv->lat[0][0], sv->lat[0][1], sv->lat[1][0], sv->lat[1][1], sv->rho_r, sv->rho_b,
+                    sv->u, sv->psi, sv->snu, sv->stage})
+    if (p) (void)hipFree(p);
+  delete sv;
+  return LBM_OK;
+}
+
+// host AoS state in the reference's shapes: f_r, f_b [R][C][9] (adv_f), rho_r, rho_b [R][C], u [R][C][2]
+int lbm_cg_solver_set_state(lbm_cg_solver* sv, const double* f_r, const double* f_b,
+                            const double* rho_r, const double* rho_b, const double* u) {
+  LBM_REQUIRE(sv && f_r && f_b && rho_r && rho_b && u, "lbm_cg_solver_set_state: NULL argument");
+  const int R = sv->g.R, C = sv->g.C;
+  const size_t n = (size_t)R * C;
+  const double* fs[2] = {f_r, f_b};
+  for (int k = 0; k < 2; ++k) {
+    LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, fs[k], n * 72, hipMemcpyHostToDevice, sv->st));
+    int rc = lbm_aos_to_soa_ex(sv->lat[sv->cur][k], sv->stage, R, C, 9, sv->g.plane_stride, sv->st);
+    if (rc) return rc;
+  }
+  LBM_CHECK_HIP(hipMemcpyAsync(sv->rho_r, rho_r, n * 8, hipMemcpyHostToDevice, sv->st));
+  LBM_CHECK_HIP(hipMemcpyAsync(sv->rho_b, rho_b, n * 8, hipMemcpyHostToDevice, sv->st));
+  LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, u, n * 16, hipMemcpyHostToDevice, sv->st));
+  int rc = lbm_aos_to_soa(sv->u, sv->stage, R, C, 2, sv->st);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  sv->post = false;
+  return LBM_OK;
+}
+
+int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps) {
+  LBM_REQUIRE(sv && n_steps >= 0, "lbm_cg_solver_step: bad argument");
+  for (int i = 0; i < n_steps; ++i) {
+    double** src = sv->lat[sv->cur];
+    double** dst = sv->lat[sv->cur ^ 1];
+    int rc;
+    if (!sv->post) {  // iteration on the given (rho, u): the driver's first pass through :431-464
+      rc = lbm_cg_collide(dst[0], dst[1], src[0], src[1], sv->rho_r, sv->rho_b, sv->u, &sv->g,
+                          &sv->bc, &sv->prm, sv->psi, sv->snu, sv->st);
+    } else {
+      rc = lbm_cg_stream_moments(sv->rho_r, sv->rho_b, sv->u, src[0], src[1], &sv->g, &sv->bc,
+                                 &sv->prm, sv->st);
+      if (rc) return rc;
+      rc = lbm_cg_stream_collide(dst[0], dst[1], src[0], src[1], sv->rho_r, sv->rho_b, sv->u,
+                                 &sv->g, &sv->bc, &sv->prm, sv->psi, sv->snu, sv->st);
+    }
+    if (rc) return rc;
+    sv->cur ^= 1;
+    sv->post = true;
+    ++sv->steps;
+  }
+  return LBM_OK;
+}
+
+// State as the reference holds it after its loop ran: adv_f of both colours, rho_r, rho_b, u
+// (all refreshed from the streamed populations, :466-477) and the last psi / s_nu.
+// Any output pointer may be NULL.
+int lbm_cg_solver_get_state(lbm_cg_solver* sv, double* f_r, double* f_b, double* rho_r,
+                            double* rho_b, double* u, double* psi, double* snu) {
+  LBM_REQUIRE(sv, "lbm_cg_solver_get_state: NULL solver");
+  const int R = sv->g.R, C = sv->g.C;
+  const size_t n = (size_t)R * C;
+  double* fo[2] = {f_r, f_b};
+  double* scratch = sv->lat[sv->cur ^ 1][0];
+  for (int k = 0; k < 2; ++k) {
+    if (!fo[k]) continue;
+    const double* src = sv->lat[sv->cur][k];
+    if (sv->post) {
+      int rc = lbm_stream(scratch, src, &sv->g, &sv->bc, sv->st);
+      if (rc) return rc;
+      src = scratch;
+    }
+    int rc = lbm_soa_to_aos_ex(sv->stage, src, R, C, 9, sv->g.plane_stride, sv->st);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipMemcpyAsync(fo[k], sv->stage, n * 72, hipMemcpyDeviceToHost, sv->st));
+    LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  }
+  if (rho_r || rho_b || u) {
+    if (sv->post) {
+      int rc = lbm_cg_stream_moments(sv->rho_r, sv->rho_b, sv->u, sv->lat[sv->cur][0],
+                                     sv->lat[sv->cur][1], &sv->g, &sv->bc, &sv->prm, sv->st);
+      if (rc) return rc;
+    }
+    if (rho_r) LBM_CHECK_HIP(hipMemcpyAsync(rho_r, sv->rho_r, n * 8, hipMemcpyDeviceToHost, sv->st));
+    if (rho_b) LBM_CHECK_HIP(hipMemcpyAsync(rho_b, sv->rho_b, n * 8, hipMemcpyDeviceToHost, sv->st));
+    if (u) {
+      int rc = lbm_soa_to_aos(sv->stage, sv->u, R, C, 2, sv->st);
+      if (rc) return rc;
+      LBM_CHECK_HIP(hipMemcpyAsync(u, sv->stage, n * 16, hipMemcpyDeviceToHost, sv->st));
+    }
+  }
+  if (psi) LBM_CHECK_HIP(hipMemcpyAsync(psi, sv->psi, n * 8, hipMemcpyDeviceToHost, sv->st));
+  if (snu) LBM_CHECK_HIP(hipMemcpyAsync(snu, sv->snu, n * 8, hipMemcpyDeviceToHost, sv->st));
+  LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  return LBM_OK;
+}
+
+int lbm_cg_solver_sync(lbm_cg_solver* sv) {
+  LBM_REQUIRE(sv, "lbm_cg_solver_sync: NULL solver");
+  LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  return LBM_OK;
+}
+
+}  // extern "C"

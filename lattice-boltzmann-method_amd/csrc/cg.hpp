@@ -1,0 +1,269 @@
+// Colour-gradient MRT two-phase step (BASELINE config 4): device restatement of the loop body
+// of test/mrtcg_rayleigh_taylor.cpp:431-477 together with src/colour.cpp and the 5x5 stencils
+// of src/differential.{hpp,cpp}.  The reference runs ~400 ATen launches per step, a per-node
+// 9x9 S tensor (81 doubles/node) and 10 padded conv2d calls; here a step is two kernels:
+//
+//   pass A  k_cg_stream_moments : stream both colours (pull + the driver's BCs), reduce to
+//           rho_r, rho_b, u (= (sum f c)/rho + Fg/(2 rho))                 reads 18, writes 4
+//   pass B  k_cg_stream_collide : LDS tile of (psi, Q_r, Q_b) with a +-2 halo built from the
+//           4 macroscopic fields (replicate-clamped at the global edges); 5x5
+//           derivatives from LDS; re-stream the 18 populations; MRT relaxation with the
+//           constant M / M^-1 unrolled and the diagonal S in registers; perturbation,
+//           recolouring, gravity source; write both colours               reads 18+4h, writes 18
+//
+// = 496 B/LUP + stencil halo ("two-pass" figure of SURVEY 8d).  Every non-standard formula of
+// the driver is kept (Q5 column copy, Q6 equilibrium, Q7 unweighted source, Q11 omega blend).
+#pragma once
+#include "d2q9.hpp"
+
+namespace lbm {
+
+struct CgColour {
+  double rho_0, alpha, beta, qcoef;  // qcoef = 1.8 alpha - 0.8 (update_C, :326-327)
+  double phi[Q], eta[Q];             // src/colour.cpp:49-64
+};
+struct CgConsts {
+  CgColour k[2];  // 0 = red, 1 = blue
+  double sigma, g;
+  double delta, r_omega, b_omega, s1, s2, s3, t2, t3;  // relaxation_function :34-101
+  double unitx[Q], unity[Q];                           // unit_E :176-178
+};
+
+inline CgConsts make_cg_consts(const lbm_cg_params& p) {
+  CgConsts c;
+  const lbm_cg_colour* src[2] = {&p.red, &p.blue};
+  double omega[2];
+  for (int i = 0; i < 2; ++i) {
+    CgColour& k = c.k[i];
+    k.rho_0 = src[i]->rho_0;
+    k.alpha = src[i]->alpha;
+    k.beta = src[i]->beta;
+    k.qcoef = 1.8 * k.alpha - 0.8;
+    const double cs2 = 3.0 * (1.0 - k.alpha) / 5.0;  // colour.cpp:37
+    const double a = 0.2 * (1.0 - k.alpha), b = 0.05 * (1.0 - k.alpha);
+    const double ph[Q] = {k.alpha, a, a, a, a, b, b, b, b};
+    for (int q = 0; q < Q; ++q) {
+      k.phi[q] = ph[q];
+      const double e2 = (double)(icx(q) * icx(q) + icy(q) * icy(q));
+      k.eta[q] = 1.0 + 0.5 * (3.0 * cs2 - 1.0) * (3.0 * e2 - 4.0);  // colour.cpp:49-54
+    }
+    omega[i] = 1.0 / (0.5 + src[i]->nu / cs2);  // init_omega :57-58
+  }
+  c.sigma = p.sigma;
+  c.g = p.gravity;
+  c.delta = p.delta;
+  c.r_omega = omega[0];
+  c.b_omega = omega[1];
+  c.s1 = 2.0 * c.r_omega * c.b_omega / (c.r_omega + c.b_omega);
+  c.s2 = 2.0 * (c.r_omega - c.s1) / c.delta;
+  c.s3 = -c.s2 / (2.0 * c.delta);
+  c.t2 = 2.0 * (c.s1 - c.b_omega) / c.delta;
+  c.t3 = c.t2 / (2.0 * c.delta);
+  for (int q = 0; q < Q; ++q) {
+    const double d = q < 5 ? 1.0 : std::sqrt(2);
+    c.unitx[q] = (double)icx(q) / d;
+    c.unity[q] = (double)icy(q) / d;
+  }
+  return c;
+}
+
+// eval_equilibrium, mrtcg_rayleigh_taylor.cpp:233-247 (9 (c.u)^2 - 3 u.u: SURVEY Q6)
+__device__ __forceinline__ void cg_feq(double (&e)[Q], double rho_k, const CgColour& k, double ux,
+                                       double uy) {
+  const double uu = ux * ux + uy * uy;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+    e[q] = rho_k * (k.phi[q] + wq(q) * (3.0 * cu * k.eta[q] + 9.0 * (cu * cu) - 3.0 * uu));
+  }
+}
+
+__device__ __forceinline__ double cg_psi(const CgConsts& c, double rr, double rb) {  // :212-225
+  return (rr / c.k[0].rho_0 - rb / c.k[1].rho_0) / (rr / c.k[0].rho_0 + rb / c.k[1].rho_0);
+}
+__device__ __forceinline__ double cg_snu(const CgConsts& c, double psi) {  // :84-100
+  double v = 0.0;
+  if (psi > c.delta) v = c.r_omega;
+  if (c.delta >= psi && psi > 0.0) v = c.s1 + c.s2 * psi + c.s3 * psi * psi;
+  if (0.0 >= psi && psi >= -c.delta) v = c.s1 + c.t2 * psi + c.t3 * psi * psi;
+  if (psi < -c.delta) v = c.b_omega;
+  return v;
+}
+
+// M and 36 M^-1 of the driver (:130-140, :146-156), compile-time tables
+__device__ __forceinline__ constexpr double cg_M(int a, int q) {
+  constexpr double M[Q][Q] = {{1, 1, 1, 1, 1, 1, 1, 1, 1},     {-4, -1, -1, -1, -1, 2, 2, 2, 2},
+                              {4, -2, -2, -2, -2, 1, 1, 1, 1}, {0, 1, 0, -1, 0, 1, -1, -1, 1},
+                              {0, -2, 0, 2, 0, 1, -1, -1, 1},  {0, 0, 1, 0, -1, 1, 1, -1, -1},
+                              {0, 0, -2, 0, 2, 1, 1, -1, -1},  {0, 1, -1, 1, -1, 0, 0, 0, 0},
+                              {0, 0, 0, 0, 0, 1, -1, 1, -1}};
+  return M[a][q];
+}
+__device__ __forceinline__ constexpr double cg_Mi36(int q, int a) {
+  constexpr double Mi[Q][Q] = {{4, -4, 4, 0, 0, 0, 0, 0, 0},    {4, -1, -2, 6, -6, 0, 0, 9, 0},
+                               {4, -1, -2, 0, 0, 6, -6, -9, 0}, {4, -1, -2, -6, 6, 0, 0, 9, 0},
+                               {4, -1, -2, 0, 0, -6, 6, -9, 0}, {4, 2, 1, 6, 3, 6, 3, 0, 9},
+                               {4, 2, 1, -6, -3, 6, 3, 0, -9},  {4, 2, 1, -6, -3, -6, -3, 0, 9},
+                               {4, 2, 1, 6, 3, -6, -3, 0, -9}};
+  return Mi[q][a];
+}
+__device__ __forceinline__ constexpr double cg_B(int q) {  // :158-163
+  return q == 0 ? -4.0 / 27.0 : (q < 5 ? 2.0 / 27.0 : 5.0 / 108.0);
+}
+// 5x5 isotropic stencil weights (xi / 5040, differential.hpp:9-16)
+__device__ __forceinline__ constexpr double cg_xi(int i, int j) {
+  constexpr double XI[5][5] = {{1.0, 32.0, 84.0, 32.0, 1.0},
+                               {32.0, 448.0, 960.0, 448.0, 32.0},
+                               {84.0, 960.0, 0.0, 960.0, 84.0},
+                               {32.0, 448.0, 960.0, 448.0, 32.0},
+                               {1.0, 32.0, 84.0, 32.0, 1.0}};
+  return XI[i][j];
+}
+
+// ---- pass A ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cg_stream_moments(
+    double* __restrict__ rho_r, double* __restrict__ rho_b, double* __restrict__ u,
+    const double* __restrict__ p_r, const double* __restrict__ p_b, Geom g, Bc bc, double grav) {
+  const long n = (long)g.R * g.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int r = (int)(i / g.C), c = (int)(i % g.C);
+    double fr[Q], fb[Q];
+    gather_bc(fr, p_r, g, bc, r, c);
+    gather_bc(fb, p_b, g, bc, r, c);
+    double rr, rb, jx, jy, ft[Q];
+    BgkModel::moments(fr, rr, jx, jy);  // r.rho = r.adv_f.sum(-1), :472
+    BgkModel::moments(fb, rb, jx, jy);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ft[q] = fr[q] + fb[q];  // calc_u(u, r.adv_f + b.adv_f, rho) :476
+    double dummy;
+    BgkModel::moments(ft, dummy, jx, jy);
+    const double rt = rr + rb;  // :474
+    rho_r[i] = rr;
+    rho_b[i] = rb;
+    u[i] = jx / rt + 0.5 * grav / rt;      // :477, Fg = (g, 0)
+    u[n + i] = jy / rt + 0.5 * 0.0 / rt;
+  }
+}
+
+// ---- pass B ---------------------------------------------------------------------------------
+constexpr int CG_TR = 8, CG_TC = 32;               // tile of nodes per 256-thread block
+constexpr int CG_LR = CG_TR + 4, CG_LC = CG_TC + 4;  // with the +-2 stencil halo
+
+template <bool FROM_POST, bool WITH_FIELDS>
+__global__ __launch_bounds__(256) void k_cg_collide(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, const double* __restrict__ rho_r,
+    const double* __restrict__ rho_b, const double* __restrict__ u, Geom g, Bc bc, CgConsts cc,
+    double* __restrict__ psi_out, double* __restrict__ snu_out) {
+  __shared__ double s_psi[CG_LR][CG_LC + 1];
+  __shared__ double s_q[4][CG_LR][CG_LC + 1];  // Qx_r, Qy_r, Qx_b, Qy_b
+  const int tiles_c = (g.C + CG_TC - 1) / CG_TC;
+  const int r_base = (blockIdx.x / tiles_c) * CG_TR, c_base = (blockIdx.x % tiles_c) * CG_TC;
+  const long n = (long)g.R * g.C;
+  // stage the stencil inputs; replicate padding = clamp (differential.cpp:5-9)
+  for (int i = threadIdx.x; i < CG_LR * CG_LC; i += 256) {
+    const int lr = i / CG_LC, lc = i % CG_LC;
+    int gr = r_base + lr - 2, gc = c_base + lc - 2;
+    gr = gr < 0 ? 0 : (gr > g.R - 1 ? g.R - 1 : gr);
+    gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
+    const long o = (long)gr * g.C + gc;
+    const double rr = rho_r[o], rb = rho_b[o], ux = u[o], uy = u[n + o];
+    s_psi[lr][lc] = cg_psi(cc, rr, rb);
+    s_q[0][lr][lc] = cc.k[0].qcoef * rr * ux;  // (1.8 alpha - 0.8) * rho_k * u_x  (:326)
+    s_q[1][lr][lc] = cc.k[0].qcoef * rr * uy;
+    s_q[2][lr][lc] = cc.k[1].qcoef * rb * ux;
+    s_q[3][lr][lc] = cc.k[1].qcoef * rb * uy;
+  }
+  __syncthreads();
+  const int tr = threadIdx.x / CG_TC, tc = threadIdx.x % CG_TC;
+  const int r = r_base + tr, c = c_base + tc;
+  if (r >= g.R || c >= g.C) return;
+
+  // 5x5 cross-correlations, taps in (i, j) row-major order as conv2d lays them out
+  double gx = 0.0, gy = 0.0, dxq[2] = {0.0, 0.0}, dyq[2] = {0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const double wx = ((1.0 / 5040.0) * cg_xi(i, j)) * (double)(i - 2);  // d/d(row)  ("x")
+      const double wy = ((1.0 / 5040.0) * cg_xi(i, j)) * (double)(j - 2);  // d/d(col)  ("y")
+      if (i != 2) {
+        gx += wx * s_psi[tr + i][tc + j];
+        dxq[0] += wx * s_q[0][tr + i][tc + j];
+        dxq[1] += wx * s_q[2][tr + i][tc + j];
+      }
+      if (j != 2) {
+        gy += wy * s_psi[tr + i][tc + j];
+        dyq[0] += wy * s_q[1][tr + i][tc + j];
+        dyq[1] += wy * s_q[3][tr + i][tc + j];
+      }
+    }
+
+  const long o = (long)r * g.C + c;
+  const double rr = rho_r[o], rb = rho_b[o], ux = u[o], uy = u[n + o];
+  const double rt = rr + rb;
+  const double psi = s_psi[tr + 2][tc + 2];
+  const double s_nu = cg_snu(cc, psi);
+  const double S[Q] = {0.0, 1.25, 1.14, 0.0, 1.6, 0.0, 1.6, s_nu, s_nu};  // :384-386, :227-231
+
+  double f[2][Q], om1[2][Q];
+  if (FROM_POST) {
+    gather_bc(f[0], in_r, g, bc, r, c);
+    gather_bc(f[1], in_b, g, bc, r, c);
+  } else {
+    const long lo = g.at(r, c);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      f[0][q] = in_r[q * g.plane + lo];
+      f[1][q] = in_b[q * g.plane + lo];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double feq[Q], m[Q];
+    cg_feq(feq, k ? rb : rr, cc.k[k], ux, uy);  // :431-432
+#pragma unroll
+    for (int a = 0; a < Q; ++a) {                // eval_mrt_operator :249-261
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) s += cg_M(a, q) * (feq[q] - f[k][q]);
+      double Ck = 0.0;                           // update_C :320-336
+      if (a == 1) Ck = 3.0 * (1.0 - 0.5 * 1.25) * (dxq[k] + dyq[k]);
+      if (a == 7) Ck = (1.0 - 0.5 * s_nu) * (dxq[k] - dyq[k]);
+      m[a] = S[a] * s + Ck;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < Q; ++a) s += ((1.0 / 36.0) * cg_Mi36(q, a)) * m[a];
+      om1[k][q] = s;
+    }
+  }
+  const double gnorm = sqrt(gx * gx + gy * gy);  // :444-447
+  const double A = 4.5 * cc.sigma * s_nu;        // :450
+  const long lo = g.at(r, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double gE = gx * (double)icx(q) + gy * (double)icy(q);
+    const double t1 = gE / (1e-20 + gnorm);
+    const double xi = 0.5 * gnorm * (wq(q) * (t1 * t1) - cg_B(q));  // eval_xi :290-300
+    const double om2 = A * xi;                                        // :263-273
+    const double gU = gx * cc.unitx[q] + gy * cc.unity[q];
+    const double kappa = (rr * rb * gU * (rr * cc.k[0].phi[q] + rb * cc.k[1].phi[q])) /
+                         ((rt * rt) * (1e-20 + gnorm));               // eval_kappa :302-318
+    const double tot = f[0][q] + om1[0][q] + om2 + f[1][q] + om1[1][q] + om2;  // :455
+    const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+    const double FgE = cc.g * (double)icx(q) + 0.0 * (double)icy(q);
+    const double uFg = ux * cc.g + uy * 0.0;
+    const double Fq = (1 - 0.5 * s_nu) * ((3.0 + 9.0 * cu) * FgE - 3.0 * uFg) * wq(q);  // :460-462
+    pn_r[q * g.plane + lo] = (rr * tot / rt + cc.k[0].beta * kappa) + Fq;  // :275-288, :463
+    pn_b[q * g.plane + lo] = (rb * tot / rt + cc.k[1].beta * kappa) + Fq;  // :464
+  }
+  if (WITH_FIELDS) {
+    psi_out[o] = psi;
+    snu_out[o] = s_nu;
+  }
+}
+
+}  // namespace lbm

@@ -177,3 +177,48 @@ class Solver:
         a, b, g = _dp(), _dp(), Geom()
         self.lib.solver_lattices(self.h, ct.byref(a), ct.byref(b), ct.byref(g))
         return ct.cast(a, ct.c_void_p).value, ct.cast(b, ct.c_void_p).value, g
+
+
+def cg_params(red=(3.0, 0.7, 0.04, 0.7), blue=(1.0, 0.1, 0.04, -0.7), sigma=0.1, gravity=6.25e-6,
+              delta=0.1):
+    """[red]/[blue] of mrtcg-rayleigh-taylor-gamma3.toml as (rho_0, alpha, nu, beta); sigma and
+    gravity are this build's recorded choices for the keys the shipped TOML lacks."""
+    return CgParams(CgColour(*red), CgColour(*blue), sigma, gravity, delta)
+
+
+class CgSolver:
+    """Python face of lbm_cg_solver: the two-phase driver loop, numpy AoS in/out."""
+
+    def __init__(self, lib, R, C, params, bc=None, stream=None):
+        self.lib, self.R, self.C, self.params = lib, R, C, params
+        self.g = Geom(R, C, 0)
+        self.h = ct.c_void_p()
+        lib.cg_solver_create(ct.byref(self.h), ct.byref(self.g), ct.byref(bc) if bc is not None else None,
+                             ct.byref(params), _stream(stream))
+
+    def close(self):
+        if self.h:
+            self.lib.cg_solver_destroy(self.h)
+            self.h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_state(self, f_r, f_b, rho_r, rho_b, u):
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in (f_r, f_b, rho_r, rho_b, u)]
+        self.lib.cg_solver_set_state(self.h, *[_hptr(a) for a in arrs])
+
+    def step(self, n):
+        self.lib.cg_solver_step(self.h, int(n))
+
+    def get_state(self):
+        R, C = self.R, self.C
+        out = dict(f_r=np.empty((R, C, 9)), f_b=np.empty((R, C, 9)), rho_r=np.empty((R, C)),
+                   rho_b=np.empty((R, C)), u=np.empty((R, C, 2)), psi=np.empty((R, C)),
+                   s_nu=np.empty((R, C)))
+        self.lib.cg_solver_get_state(self.h, *[_hptr(out[k]) for k in
+                                               ("f_r", "f_b", "rho_r", "rho_b", "u", "psi", "s_nu")])
+        return out
