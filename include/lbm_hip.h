@@ -118,6 +118,9 @@ typedef struct lbm_bc {
 typedef struct lbm_bgk_params {
   double omega;
   int incompressible; /* 0: calc_u + equilibrium; 1: calc_incomp_u + incomp_equilibrium */
+  int delta_form;     /* how the driver writes the relaxation (different rounding, same maths):
+                         0: f* = (1-omega) f + omega feq        solver::collision, solver.cpp:73
+                         1: f* = f + (-omega (f - feq))          cylinder_test.cpp:108,123-125 */
 } lbm_bgk_params;
 
 /* P = collide(f): moments, equilibrium, collision of every node in place of one driver
@@ -202,6 +205,32 @@ int lbm_cg_solver_get_state(lbm_cg_solver* sv, double* f_r, double* f_b, double*
                             double* rho_b, double* u, double* psi, double* s_nu);
 int lbm_cg_solver_sync(lbm_cg_solver* sv);
 
+/* ---- immersed boundary, multi-direct forcing (src/ibm.cpp; BASELINE config 5) ---------------
+ * The reference loops over the markers on the HOST (~10 ATen launches per marker per forcing
+ * iteration, ibm.cpp:166-187).  Here: markers, their 4x4 Peskin weight boxes and a per-node
+ * CSR list of (marker, tap) pairs live on the device; one forcing iteration is two kernels
+ * (interpolate + force per marker; gather-spread + velocity update per ROI node).  Spreading is
+ * a GATHER in marker order, so the sums are bit-reproducible and equal the reference's
+ * sequential accumulation -- no atomics.  The boundary is stationary (f_j = -2 rho_j u_j,
+ * SURVEY Q10) and the weights keep the reference's transposed kernel (Q9). */
+typedef struct lbm_ibm lbm_ibm;
+/* x[i], y[i]: marker row / column coordinates (TOML arrays "x", "y", ibm.cpp:78-102);
+ * m_max: ibm.hpp:25 default 5 (m_max - 1 forcing iterations); X, Y: lattice size */
+int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
+                   int X, int Y);
+int lbm_ibm_destroy(lbm_ibm* ib);
+/* region of interest rows [r0, r1), columns [c0, c1)  (ibm.cpp:104-156) */
+int lbm_ibm_roi(const lbm_ibm* ib, int* r0, int* r1, int* c0, int* c1);
+/* eulerian_force_density (ibm.cpp:158-190): u[2][X][Y], rho[X][Y] device SoA ->
+ * F kept inside the context; F_out (may be NULL) receives it as [2][ROI_r][ROI_c] */
+int lbm_ibm_force(lbm_ibm* ib, const double* u, const double* rho, double* F_out, lbm_stream_t s);
+/* Guo source of the driver on the ROI (cylinder_test.cpp:116-127):
+ * p[q][roi] += (1 - omega/2) w_q [ (a + b c_q.u)(c_q.F) - a u.F ]  with the UNcorrected u */
+int lbm_ibm_add_source(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, double omega,
+                       double a, double b, lbm_stream_t s);
+/* F_s = sum over the ROI of F (drag, lift), cylinder_test.cpp:112; host out[2], synchronises */
+int lbm_ibm_surface_force(lbm_ibm* ib, double* out2, lbm_stream_t s);
+
 /* ---- solver context: one block, two lattices, the driver loop ----------------------------
  * Replaces the hand-written time loops of the reference drivers (e.g.
  * horizontal_poiseuille_test.cpp:100-153).  The context keeps POST-collision populations
@@ -225,6 +254,10 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments);
 /* host AoS rho[R][C], u[R][C][2] recorded by the last step(.., 1) */
 int lbm_solver_get_moments_aos(lbm_solver* sv, double* rho_host, double* u_host);
 int lbm_solver_sync(lbm_solver* sv);
+/* attach an immersed boundary to a BGK solver: every step then runs lbm_ibm_force on the
+ * step's moments and adds the Guo source (a, b) on the ROI, as cylinder_test.cpp:110-127.
+ * The solver does not take ownership. */
+int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_b);
 /* device pointers of the resident lattices (current post-collision, scratch) for callers
  * that drive lbm_*_stream_collide themselves (benchmarks, multi-GPU slabs) */
 int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* geom /* may be NULL */);

@@ -72,7 +72,7 @@ int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
                     const lbm_bgk_params* prm, double* rho, double* u, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_collide", prm);
   if (rc) return rc;
-  const BgkModel m{prm->omega, prm->incompressible};
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form};
   rc = launch_collide_only("lbm_bgk_collide", p, f, g, bc, m, rho, u, as_stream(s));
   if (rc) return rc;
   if (bc && bc->pressure_rows) {
@@ -88,7 +88,7 @@ int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            int row_end, double* rho, double* u, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_stream_collide", prm);
   if (rc) return rc;
-  const BgkModel m{prm->omega, prm->incompressible};
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form};
   rc = launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, m, row_begin, row_end,
                              rho, u, as_stream(s));
   if (rc) return rc;

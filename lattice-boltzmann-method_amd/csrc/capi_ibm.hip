@@ -1,0 +1,295 @@
+// C ABI, part 6: immersed boundary, multi-direct forcing (src/ibm.cpp) and its coupling to the
+// BGK step (test/cylinder_test.cpp:110-127).  See include/lbm_hip.h for the design note.
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "d2q9.hpp"
+#include "internal.hpp"
+
+namespace lbm {
+
+// 4-point Peskin kernel, ibm.cpp:39-45
+static double peskin4(double r_) {
+  const double r = std::abs(r_);
+  if (r <= 1) return 0.125 * (3.0 - 2.0 * r + std::sqrt(1.0 + 4.0 * r - 4.0 * r * r));
+  else if (r <= 2) return 0.125 * (5.0 - 2.0 * r - std::sqrt(-7.0 + 12.0 * r - 4.0 * r * r));
+  return 0.0;
+}
+
+struct IbmDev {
+  int n_markers, RR, RC, r0, c0, X, Y;
+  const int* box0;     // [n_markers] ROI-flat index of the box's first node (row0 * RC + col0)
+  const double* phi;   // [n_markers][16], k = i*4 + j over the box flattened [row i][col j]
+  const int* csr_ptr;  // [RR*RC + 1]
+  const int* csr_mk;   // [nnz] marker of each (node, tap) pair, ascending per node
+  const double* csr_w; // [nnz] its weight phi
+};
+
+// u, rho of the ROI window copied out of the full fields (ibm.cpp:163-164); F_sum = 0
+__global__ __launch_bounds__(256) void k_ibm_begin(IbmDev d, const double* __restrict__ u,
+                                                   const double* __restrict__ rho,
+                                                   double* __restrict__ u_roi,
+                                                   double* __restrict__ rho_roi,
+                                                   double* __restrict__ F_sum) {
+  const int n = d.RR * d.RC;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int r = i / d.RC, c = i % d.RC;
+  const long s = (long)(d.r0 + r) * d.Y + (d.c0 + c), N = (long)d.X * d.Y;
+  u_roi[i] = u[s];
+  u_roi[n + i] = u[N + s];
+  rho_roi[i] = rho[s];
+  F_sum[i] = 0.0;
+  F_sum[n + i] = 0.0;
+}
+
+// per marker: interpolate u_j, rho_j over its 4x4 box (taps in k order, as matmul(phi, box)),
+// f_j = -2 rho_j u_j   (ibm.cpp:171-177)
+__global__ __launch_bounds__(64) void k_ibm_interp(IbmDev d, const double* __restrict__ u_roi,
+                                                   const double* __restrict__ rho_roi,
+                                                   double* __restrict__ fj) {
+  const int j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= d.n_markers) return;
+  const int n = d.RR * d.RC, b0 = d.box0[j];
+  double ujx = 0.0, ujy = 0.0, rhoj = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int node = b0 + (k / 4) * d.RC + (k % 4);
+    const double w = d.phi[j * 16 + k];
+    ujx += w * u_roi[node];
+    ujy += w * u_roi[n + node];
+    rhoj += w * rho_roi[node];
+  }
+  fj[j] = -2.0 * rhoj * ujx;
+  fj[d.n_markers + j] = -2.0 * rhoj * ujy;
+}
+
+// per ROI node: F_n = sum over its (marker, tap) pairs in marker order (== the reference's
+// sequential "F[box] += phi f_j", ibm.cpp:180-182); u += F_n / (2 rho); F_sum += F_n (:186,:189)
+__global__ __launch_bounds__(256) void k_ibm_spread(IbmDev d, const double* __restrict__ fj,
+                                                    double* __restrict__ u_roi,
+                                                    const double* __restrict__ rho_roi,
+                                                    double* __restrict__ F_sum) {
+  const int n = d.RR * d.RC;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double fx = 0.0, fy = 0.0;
+  for (int e = d.csr_ptr[i]; e < d.csr_ptr[i + 1]; ++e) {
+    const int j = d.csr_mk[e];
+    const double w = d.csr_w[e];
+    fx += w * fj[j];
+    fy += w * fj[d.n_markers + j];
+  }
+  const double rh = rho_roi[i];
+  u_roi[i] += 0.5 * fx / rh;
+  u_roi[n + i] += 0.5 * fy / rh;
+  F_sum[i] += fx;
+  F_sum[n + i] += fy;
+}
+
+// cylinder_test.cpp:116-127: S = ((1-0.5w)((a + b u.c)(F.c) - a (u.F)) E); f_coll[ROI] += S
+__global__ __launch_bounds__(256) void k_ibm_add_source(IbmDev d, double* __restrict__ p, Geom g,
+                                                        const double* __restrict__ u,
+                                                        const double* __restrict__ F_sum,
+                                                        double omega, double a, double b) {
+  const int n = d.RR * d.RC;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int r = d.r0 + i / d.RC, c = d.c0 + i % d.RC;
+  const long s = (long)r * d.Y + c, N = (long)d.X * d.Y;
+  const double ux = u[s], uy = u[N + s], Fx = F_sum[i], Fy = F_sum[n + i];
+  const double uF = ux * Fx + uy * Fy;
+  const long o = g.at(r, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+    const double cF = Fx * (double)icx(q) + Fy * (double)icy(q);
+    p[q * g.plane + o] += ((1 - 0.5 * omega) * ((a + b * cu) * cF - a * uF) * wq(q));
+  }
+}
+
+// F_s = F.reshape(-1, 2).sum(0): one block, fixed-order tree -> reproducible
+__global__ __launch_bounds__(256) void k_ibm_sum(int n, const double* __restrict__ F_sum,
+                                                 double* __restrict__ out2) {
+  __shared__ double sx[256], sy[256];
+  double ax = 0.0, ay = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    ax += F_sum[i];
+    ay += F_sum[n + i];
+  }
+  sx[threadIdx.x] = ax;
+  sy[threadIdx.x] = ay;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sx[threadIdx.x] += sx[threadIdx.x + s];
+      sy[threadIdx.x] += sy[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = sx[0];
+    out2[1] = sy[0];
+  }
+}
+
+}  // namespace lbm
+
+struct lbm_ibm {
+  lbm::IbmDev d;
+  int m_max, r1, c1;
+  void* dev_blob;                  // all constant device arrays in one allocation
+  double *u_roi, *rho_roi, *F_sum, *fj, *out2;  // device work arrays
+};
+
+using namespace lbm;
+
+extern "C" {
+
+int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
+                   int X, int Y) {
+  LBM_REQUIRE(out && x && y && n_markers > 0, "lbm_ibm_create: bad argument");
+  LBM_REQUIRE(m_max >= 2, "lbm_ibm_create: m_max=%d (need >= 2 for one forcing iteration)", m_max);
+  // ROI, ibm.cpp:124-153
+  long r_min = 1000000, r_max = 0, c_min = 1000000, c_max = 0;
+  for (int i = 0; i < n_markers; ++i) {
+    const int fx = (int)std::floor(x[i]), fy = (int)std::floor(y[i]);
+    r_min = std::min<long>(r_min, fx - 2);
+    r_max = std::max<long>(r_max, fx + 2);
+    c_min = std::min<long>(c_min, fy - 2);
+    c_max = std::max<long>(c_max, fy + 2);
+  }
+  LBM_REQUIRE(r_min >= 1 && c_min >= 1 && r_max + 1 <= X - 1 && c_max + 1 <= Y - 1,
+              "lbm_ibm_create: ROI rows [%ld,%ld] cols [%ld,%ld] must lie strictly inside the %dx%d lattice",
+              r_min, r_max, c_min, c_max, X, Y);
+  const int RR = (int)(r_max - r_min + 1), RC = (int)(c_max - c_min + 1), n = RR * RC;
+  std::vector<int> box0(n_markers);
+  std::vector<double> phi((size_t)n_markers * 16);
+  std::vector<std::vector<std::pair<int, double>>> per_node(n);
+  for (int j = 0; j < n_markers; ++j) {
+    // marker::set_box with coordinates relative to the ROI origin (ibm.cpp:20-37, :116)
+    const double xr = x[j] - (double)r_min, yr = y[j] - (double)c_min;
+    const double fx = std::floor(xr), fy = std::floor(yr);
+    const int row0 = (int)fx - 1, col0 = (int)fy - 1;
+    box0[j] = row0 * RC + col0;
+    for (int k = 0; k < 16; ++k) {
+      // stencil row 0 (k%4) pairs with x, row 1 (k/4) with y, while the box is flattened
+      // [row = k/4][col = k%4]: the reference's transposed kernel, kept as is
+      const double sx = xr - ((double)(k % 4) + fx - 1.0);
+      const double sy = yr - ((double)(k / 4) + fy - 1.0);
+      const double w = peskin4(sx) * peskin4(sy);
+      phi[(size_t)j * 16 + k] = w;
+      per_node[(row0 + k / 4) * RC + (col0 + k % 4)].push_back({j, w});
+    }
+  }
+  std::vector<int> csr_ptr(n + 1, 0), csr_mk;
+  std::vector<double> csr_w;
+  for (int i = 0; i < n; ++i) {
+    for (auto& e : per_node[i]) {  // markers were visited in ascending order
+      csr_mk.push_back(e.first);
+      csr_w.push_back(e.second);
+    }
+    csr_ptr[i + 1] = (int)csr_mk.size();
+  }
+  const size_t nnz = csr_mk.size();
+
+  lbm_ibm* ib = new (std::nothrow) lbm_ibm();
+  LBM_REQUIRE(ib, "lbm_ibm_create: out of host memory");
+  ib->m_max = m_max;
+  ib->r1 = (int)r_max + 1;
+  ib->c1 = (int)c_max + 1;
+  ib->dev_blob = nullptr;
+  ib->u_roi = ib->rho_roi = ib->F_sum = ib->fj = ib->out2 = nullptr;
+  // one blob: doubles first (8-byte aligned), then ints
+  const size_t n_dbl = phi.size() + nnz, n_int = box0.size() + csr_ptr.size() + nnz;
+  const size_t blob_bytes = n_dbl * 8 + n_int * 4;
+  std::vector<char> host(blob_bytes);
+  double* hd = reinterpret_cast<double*>(host.data());
+  std::copy(phi.begin(), phi.end(), hd);
+  std::copy(csr_w.begin(), csr_w.end(), hd + phi.size());
+  int* hi = reinterpret_cast<int*>(host.data() + n_dbl * 8);
+  std::copy(box0.begin(), box0.end(), hi);
+  std::copy(csr_ptr.begin(), csr_ptr.end(), hi + box0.size());
+  std::copy(csr_mk.begin(), csr_mk.end(), hi + box0.size() + csr_ptr.size());
+  hipError_t e = hipMalloc(&ib->dev_blob, blob_bytes);
+  if (e == hipSuccess) e = hipMemcpy(ib->dev_blob, host.data(), blob_bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&ib->u_roi, (size_t)n * 16);
+  if (e == hipSuccess) e = hipMalloc(&ib->rho_roi, (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc(&ib->F_sum, (size_t)n * 16);
+  if (e == hipSuccess) e = hipMalloc(&ib->fj, (size_t)n_markers * 16);
+  if (e == hipSuccess) e = hipMalloc(&ib->out2, 16);
+  if (e != hipSuccess) {
+    set_error("lbm_ibm_create: HIP allocation/copy failed: %s", hipGetErrorString(e));
+    lbm_ibm_destroy(ib);
+    return LBM_ERR_HIP;
+  }
+  char* base = static_cast<char*>(ib->dev_blob);
+  const double* dd = reinterpret_cast<const double*>(base);
+  const int* di = reinterpret_cast<const int*>(base + n_dbl * 8);
+  ib->d = IbmDev{n_markers, RR, RC, (int)r_min, (int)c_min, X, Y, di, dd,
+                 di + box0.size(), di + box0.size() + csr_ptr.size(), dd + phi.size()};
+  *out = ib;
+  return LBM_OK;
+}
+
+int lbm_ibm_destroy(lbm_ibm* ib) {
+  if (!ib) return LBM_OK;
+  for (void* p : {ib->dev_blob, (void*)ib->u_roi, (void*)ib->rho_roi, (void*)ib->F_sum,
+                  (void*)ib->fj, (void*)ib->out2})
+    if (p) (void)hipFree(p);
+  delete ib;
+  return LBM_OK;
+}
+
+int lbm_ibm_roi(const lbm_ibm* ib, int* r0, int* r1, int* c0, int* c1) {
+  LBM_REQUIRE(ib && r0 && r1 && c0 && c1, "lbm_ibm_roi: NULL argument");
+  *r0 = ib->d.r0;
+  *r1 = ib->r1;
+  *c0 = ib->d.c0;
+  *c1 = ib->c1;
+  return LBM_OK;
+}
+
+int lbm_ibm_force(lbm_ibm* ib, const double* u, const double* rho, double* F_out, lbm_stream_t s) {
+  LBM_REQUIRE(ib && u && rho, "lbm_ibm_force: NULL argument");
+  hipStream_t st = as_stream(s);
+  const int n = ib->d.RR * ib->d.RC, nb = (n + 255) / 256;
+  LBM_KLAUNCH(k_ibm_begin, dim3(nb), dim3(256), 0, st, ib->d, u, rho, ib->u_roi, ib->rho_roi, ib->F_sum);
+  LBM_CHECK_LAUNCH();
+  for (int it = 1; it < ib->m_max; ++it) {  // ibm.cpp:166
+    LBM_KLAUNCH(k_ibm_interp, dim3((ib->d.n_markers + 63) / 64), dim3(64), 0, st, ib->d, ib->u_roi,
+                ib->rho_roi, ib->fj);
+    LBM_CHECK_LAUNCH();
+    LBM_KLAUNCH(k_ibm_spread, dim3(nb), dim3(256), 0, st, ib->d, ib->fj, ib->u_roi, ib->rho_roi, ib->F_sum);
+    LBM_CHECK_LAUNCH();
+  }
+  if (F_out)
+    LBM_CHECK_HIP(hipMemcpyAsync(F_out, ib->F_sum, (size_t)n * 16, hipMemcpyDeviceToDevice, st));
+  return LBM_OK;
+}
+
+int lbm_ibm_add_source(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, double omega,
+                       double a, double b, lbm_stream_t s) {
+  LBM_REQUIRE(ib && p && g && u, "lbm_ibm_add_source: NULL argument");
+  LBM_REQUIRE(g->R == ib->d.X && g->C == ib->d.Y && g->ghost == 0,
+              "lbm_ibm_add_source: lattice %dx%d (ghost %d) does not match the boundary's %dx%d",
+              g->R, g->C, g->ghost, ib->d.X, ib->d.Y);
+  const int n = ib->d.RR * ib->d.RC;
+  LBM_KLAUNCH(k_ibm_add_source, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), ib->d, p,
+              make_geom(*g), u, ib->F_sum, omega, a, b);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_ibm_surface_force(lbm_ibm* ib, double* out2, lbm_stream_t s) {
+  LBM_REQUIRE(ib && out2, "lbm_ibm_surface_force: NULL argument");
+  LBM_KLAUNCH(k_ibm_sum, dim3(1), dim3(256), 0, as_stream(s), ib->d.RR * ib->d.RC, ib->F_sum, ib->out2);
+  LBM_CHECK_LAUNCH();
+  LBM_CHECK_HIP(hipMemcpyAsync(out2, ib->out2, 16, hipMemcpyDeviceToHost, as_stream(s)));
+  LBM_CHECK_HIP(hipStreamSynchronize(as_stream(s)));
+  return LBM_OK;
+}
+
+}  // extern "C"

@@ -138,6 +138,7 @@ __device__ __forceinline__ bool is_edge_node(const Geom& g, int r, int c) {
 struct BgkModel {
   double omega;
   int incompressible;
+  int delta_form;  // see lbm_bgk_params
 
   __device__ __forceinline__ static void moments(const double (&f)[Q], double& rho, double& jx,
                                                  double& jy) {
@@ -177,8 +178,13 @@ struct BgkModel {
       uy = jy / rho;
     }
     feq(e, rho, ux, uy);
+    if (delta_form) {
 #pragma unroll
-    for (int q = 0; q < Q; ++q) f[q] = (1.0 - omega) * f[q] + omega * e[q];  // :73
+      for (int q = 0; q < Q; ++q) f[q] = f[q] + (-omega * (f[q] - e[q]));  // cylinder_test.cpp:108,123
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = (1.0 - omega) * f[q] + omega * e[q];  // :73
+    }
   }
   __device__ __forceinline__ void collide(double (&f)[Q], double& rho, double& ux, double& uy) const {
     double e[Q];

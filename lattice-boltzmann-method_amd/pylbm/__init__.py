@@ -41,7 +41,10 @@ class Bc(ct.Structure):
 
 
 class BgkParams(ct.Structure):
-    _fields_ = [("omega", ct.c_double), ("incompressible", ct.c_int)]
+    _fields_ = [("omega", ct.c_double), ("incompressible", ct.c_int), ("delta_form", ct.c_int)]
+
+    def __init__(self, omega=1.0, incompressible=0, delta_form=0):
+        super().__init__(omega, incompressible, delta_form)
 
 
 class KbcParams(ct.Structure):
@@ -173,6 +176,11 @@ class Solver:
     def sync(self):
         self.lib.solver_sync(self.h)
 
+    def attach_ibm(self, ibm, guo_a=1.0 / 3.0, guo_b=1.0 / 9.0):
+        """defaults: the (1/3, 1/9) the cylinder driver uses (cylinder_test.cpp:66-67)"""
+        self._ibm = ibm  # keep alive
+        self.lib.solver_attach_ibm(self.h, ibm.h, ct.c_double(guo_a), ct.c_double(guo_b))
+
     def lattices(self):
         a, b, g = _dp(), _dp(), Geom()
         self.lib.solver_lattices(self.h, ct.byref(a), ct.byref(b), ct.byref(g))
@@ -222,3 +230,35 @@ class CgSolver:
         self.lib.cg_solver_get_state(self.h, *[_hptr(out[k]) for k in
                                                ("f_r", "f_b", "rho_r", "rho_b", "u", "psi", "s_nu")])
         return out
+
+
+class Ibm:
+    """Python face of lbm_ibm (immersed boundary, stationary markers)."""
+
+    def __init__(self, lib, x, y, X, Y, m_max=5):
+        self.lib = lib
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self.h = ct.c_void_p()
+        lib.ibm_create(ct.byref(self.h), _hptr(x), _hptr(y), len(x), int(m_max), int(X), int(Y))
+
+    def roi(self):
+        v = [ct.c_int() for _ in range(4)]
+        self.lib.ibm_roi(self.h, *[ct.byref(i) for i in v])
+        return tuple(i.value for i in v)
+
+    def surface_force(self, stream=None):
+        out = np.zeros(2)
+        self.lib.ibm_surface_force(self.h, _hptr(out), _stream(stream))
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.ibm_destroy(self.h)
+            self.h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
