@@ -173,6 +173,10 @@ typedef struct lbm_cg_params {
   double gravity; /* [general] gravity_magnitude  (:361), Fg = (gravity, 0) along +r (:403) */
   double delta;   /* interface half-width of the s_nu blend; the driver hard-codes 0.1 (:375) */
 } lbm_cg_params;
+/* differential::x (dir 0, d/d row) and ::y (dir 1, d/d column): isotropic 5x5 finite
+ * differences with replicate padding (src/differential.hpp:9-40, src/differential.cpp:3-33);
+ * psi, out: [R][C].  Stand-alone parity operator; the fused step has its own LDS stencil. */
+int lbm_diff5(double* out, const double* psi, int R, int C, int dir, lbm_stream_t s);
 /* the driver's boundary set (:495-533): bounce-back rows, same-row column copy */
 void lbm_cg_default_bc(lbm_bc* bc);
 /* eval_equilibrium (:233-247): f[9][R][C] (plane stride as given) from rho_k[R][C], u[2][R][C] */

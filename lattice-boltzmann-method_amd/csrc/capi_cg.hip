@@ -18,6 +18,29 @@ __global__ __launch_bounds__(256) void k_cg_equilibrium(double* __restrict__ f,
   }
 }
 
+// stand-alone differential::x / ::y (src/differential.cpp:23-33): 5x5 cross-correlation with
+// replicate padding; dir 0 = d/d(row) ("x"), 1 = d/d(col) ("y").  Same tap order as the fused
+// collide kernel.  Not on the hot path (the fused step reads its stencils from LDS).
+__global__ __launch_bounds__(256) void k_diff5(double* __restrict__ out,
+                                               const double* __restrict__ psi, int R, int C, int dir) {
+  const long n = (long)R * C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int r = (int)(idx / C), c = (int)(idx % C);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const double w = ((1.0 / 5040.0) * cg_xi(i, j)) * (double)(dir == 0 ? i - 2 : j - 2);
+        int rr = r + i - 2, cc = c + j - 2;
+        rr = rr < 0 ? 0 : (rr > R - 1 ? R - 1 : rr);
+        cc = cc < 0 ? 0 : (cc > C - 1 ? C - 1 : cc);
+        s += w * psi[(long)rr * C + cc];
+      }
+    out[idx] = s;
+  }
+}
+
 static int check_cg(const char* fn, const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* p) {
   int rc = validate_geom_bc(fn, g, bc);
   if (rc) return rc;
@@ -53,6 +76,14 @@ static int launch_cg_collide(bool from_post, double* pn_r, double* pn_b, const d
 using namespace lbm;
 
 extern "C" {
+
+int lbm_diff5(double* out, const double* psi, int R, int C, int dir, lbm_stream_t s) {
+  LBM_REQUIRE(out && psi && out != psi && R > 0 && C > 0 && (dir == 0 || dir == 1), "lbm_diff5: bad argument");
+  const long n = (long)R * C;
+  LBM_KLAUNCH(k_diff5, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), out, psi, R, C, dir);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
 
 void lbm_cg_default_bc(lbm_bc* bc) {
   // apply_boundary_conditions, mrtcg_rayleigh_taylor.cpp:495-533

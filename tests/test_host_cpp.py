@@ -1,0 +1,73 @@
+"""CPU suite: the C++ host side that needs no GPU -- the TOML-subset reader and the
+params::flow / lattice / simulation mirror (src/params.cpp) -- against an independent Python
+evaluation of the same formulas (tomli + math)."""
+import json
+import math
+import os
+import subprocess
+
+import pytest
+import tomli
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "lattice-boltzmann-method_amd")
+DUMP = os.path.join(PKG, "drivers", "bin", "params_dump")
+
+
+@pytest.fixture(scope="module")
+def dump():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "drivers"), "bin/params_dump"])
+    return DUMP
+
+
+def expected(path):
+    t = tomli.load(open(path, "rb"))
+    fl, la = t["flow"], t["lattice"]
+    nu, u, l_phys = fl["kinematic_viscosity"], fl["characteristic_velocity"], fl["characteristic_length"]
+    Re = u * l_phys / nu
+    tau, dx = la["relaxation_time"], la["lattice_spacing"]
+    l = math.ceil(l_phys / dx) if math.ceil(l_phys / dx) % 2 != 0 else math.floor(l_phys / dx)
+    cs2 = 1.0 / 3.0
+    lat_nu = cs2 * (tau - 0.5)
+    dt = cs2 * (tau - 0.5) * (dx * dx) / nu
+    out = dict(flow=dict(nu=nu, u=u, l=l_phys, rho_0=fl["initial_density"], Re=Re),
+               lattice=dict(tau=tau, omega=1.0 / tau, Re=Re, nu=lat_nu, l=l, dx=dx, dt=dt,
+                            T=math.ceil(1.0 / dt), u=Re * lat_nu / l,
+                            X=math.ceil(l * la["x_multiplier"]), Y=math.ceil(l * la["y_multiplier"])))
+    if "simulation" in t:
+        s = t["simulation"]
+        total = math.ceil(s["stop_time"] * out["lattice"]["T"])
+        snap = math.ceil(s["snapshot_period"] * out["lattice"]["T"])
+        out["simulation"] = dict(total_steps=total, snapshot_steps=snap,
+                                 total_snapshots=math.ceil(total / snap), file_prefix=s["file_prefix"])
+    return out
+
+
+def test_params_match_reference_formulas(dump):
+    path = os.path.join(PKG, "examples", "parameters.toml")
+    got = json.loads(subprocess.check_output([dump, path]))
+    want = expected(path)
+    for sect in want:
+        for k, v in want[sect].items():
+            if isinstance(v, float):
+                assert got[sect][k] == pytest.approx(v, rel=1e-15), (sect, k)
+            else:
+                assert got[sect][k] == v, (sect, k)
+    # the values SURVEY.md quotes for the reference's parameters.toml
+    assert got["lattice"]["l"] == 300 and got["lattice"]["X"] == 2700 and got["lattice"]["Y"] == 2100
+
+
+def test_missing_key_raises_like_the_reference(dump, tmp_path):
+    p = tmp_path / "bad.toml"
+    p.write_text("[flow]\ninitial_density = 1.0\nkinematic_viscosity = 1e-6\ncharacteristic_velocity = 1.0\n")
+    r = subprocess.run([dump, str(p)], capture_output=True, text=True)
+    assert r.returncode == 2
+    assert "characteristic_length not defined in parameters file" in r.stdout  # params.cpp:25
+
+
+def test_toml_arrays_quoted_tables_and_comments(dump, tmp_path):
+    p = tmp_path / "b.toml"
+    body = open(os.path.join(PKG, "examples", "parameters.toml")).read()
+    p.write_text(body + '\n["cylinder-a"]\nx = [1.5, 2.5, # comment\n  3.5,\n 4_0.0]\ny = [1, 2, 3, 4]\n')
+    got = json.loads(subprocess.check_output([dump, str(p), "cylinder-a"]))
+    assert got["n_x"] == 4 and "error" not in got
