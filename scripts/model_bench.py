@@ -1,0 +1,122 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the contract bench): MLUPS of the KBC, colour-gradient and
+IBM-cylinder steps at BASELINE config sizes on one GPU, through the solver contexts of the
+C ABI.  Prints one JSON line per model."""
+import ctypes as ct
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lattice-boltzmann-method_amd"))
+import numpy as np
+import torch
+
+import pylbm
+from pylbm import _ptr
+
+lib = pylbm.Lib()
+dev = torch.device("cuda:0")
+
+
+def timed(step, n, warm=5):
+    step(warm)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step(n)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def report(name, R, C, dt, bytes_per_lup, extra=None):
+    mlups = R * C / dt / 1e6
+    out = dict(model=name, rows=R, cols=C, ms_per_step=round(dt * 1e3, 4), MLUPS=round(mlups, 1),
+               GBs=round(mlups * 1e6 * bytes_per_lup / 1e9, 1), bytes_per_lup=bytes_per_lup,
+               frac_of_8TBs=round(mlups * 1e6 * bytes_per_lup / 8e12, 4))
+    if extra:
+        out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def smooth_f(R, C):
+    r = torch.arange(R, device=dev, dtype=torch.float64).view(-1, 1)
+    c = torch.arange(C, device=dev, dtype=torch.float64).view(1, -1)
+    u = torch.empty((2, R, C), dtype=torch.float64, device=dev)
+    u[0] = 0.03 * torch.sin(2 * np.pi * r / R) * torch.cos(2 * np.pi * c / C)
+    u[1] = -0.03 * torch.cos(2 * np.pi * r / R) * torch.sin(2 * np.pi * c / C)
+    rho = torch.ones((R, C), dtype=torch.float64, device=dev)
+    f = torch.empty((9, R, C), dtype=torch.float64, device=dev)
+    lib.equilibrium(_ptr(f), _ptr(u), _ptr(rho), R, C, None)
+    torch.cuda.synchronize()
+    return f
+
+
+def bench_single(model, name, R, C, params, n=40, bc=None):
+    sv = pylbm.Solver(lib, model, R, C, params, bc=bc)
+    f = smooth_f(R, C)
+    lib.solver_set_f_soa_dev(sv.h, _ptr(f))
+    del f
+    dt = timed(lambda k: sv.step(k), n)
+    report(name, R, C, dt, 144)
+    sv.close()
+
+
+def bench_cg(R, C, n=20):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    prm = pylbm.cg_params()
+    # init on the host like the driver (init_rho_cosine), populations via lbm_cg_equilibrium
+    rr = np.arange(R).reshape(-1, 1)
+    s = R / 2.0 - 0.1 * C * np.cos(2.0 * 3.141592 * np.arange(C) / C).reshape(1, -1)
+    rho_r = 3.0 * (rr < s)
+    rho_b = 1.0 * (rr >= s)
+    u = np.zeros((R, C, 2))
+    d_rr, d_rb = torch.from_numpy(rho_r.astype(np.float64)).to(dev), torch.from_numpy(rho_b.astype(np.float64)).to(dev)
+    d_u = torch.zeros((2, R, C), dtype=torch.float64, device=dev)
+    f_r = torch.empty((9, R, C), dtype=torch.float64, device=dev)
+    f_b = torch.empty((9, R, C), dtype=torch.float64, device=dev)
+    lib.cg_equilibrium(_ptr(f_r), _ptr(d_rr), _ptr(d_u), ct.byref(prm.red), R, C, ct.c_longlong(0), None)
+    lib.cg_equilibrium(_ptr(f_b), _ptr(d_rb), _ptr(d_u), ct.byref(prm.blue), R, C, ct.c_longlong(0), None)
+    torch.cuda.synchronize()
+    sv = pylbm.CgSolver(lib, R, C, prm)
+    sv.set_state(np.moveaxis(f_r.cpu().numpy(), 0, -1), np.moveaxis(f_b.cpu().numpy(), 0, -1), rho_r, rho_b, u)
+    del f_r, f_b
+    dt = timed(lambda k: sv.step(k), n, warm=3)
+    report("colour-gradient MRT (two-pass)", R, C, dt, 496)
+    sv.close()
+
+
+def bench_cylinder(X, Y, n=30):
+    omega, u_in = 1.0 / 0.55, 0.04
+    m = int(round(np.pi * 300))
+    t = 2 * np.pi * np.arange(m) / m
+    x, y = X / 4.0 + 150 * np.cos(t), Y / 2.0 + 150 * np.sin(t)
+    bc = pylbm.Bc.periodic()
+    bc.row_lo = bc.row_hi = pylbm.EDGE_ABB_VELOCITY
+    bc.col_lo = bc.col_hi = pylbm.EDGE_SPECULAR
+    bc.uw_r = u_in
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1), bc=bc)
+    ib = pylbm.Ibm(lib, x, y, X, Y)
+    sv.attach_ibm(ib)
+    u = torch.zeros((2, X, Y), dtype=torch.float64, device=dev); u[0] = u_in
+    rho = torch.ones((X, Y), dtype=torch.float64, device=dev)
+    f = torch.empty((9, X, Y), dtype=torch.float64, device=dev)
+    lib.incomp_equilibrium(_ptr(f), _ptr(u), _ptr(rho), X, Y, None)
+    lib.solver_set_f_soa_dev(sv.h, _ptr(f))
+    del f, u, rho
+    dt = timed(lambda k: sv.step(k), n)
+    report("BGK + IBM cylinder (d=300, %d markers)" % m, X, Y, dt, 144, dict(note="+24 B/LUP moment output every step"))
+    sv.close(); ib.close()
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["bgk", "kbc", "cg", "ibm"]
+    if "bgk" in which:
+        bench_single(pylbm.MODEL_BGK, "BGK (solver context)", 8192, 8192, pylbm.BgkParams(1.2, 0))
+    if "kbc" in which:
+        bench_single(pylbm.MODEL_KBC, "KBC", 4096, 4096, pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+    if "cg" in which:
+        bench_cg(8192, 2048)
+    if "ibm" in which:
+        bench_cylinder(16384 // 8, 4096)   # one 8-GPU slab of config 5
+        bench_cylinder(4096, 4096)
