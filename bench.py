@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--tune", action="append", default=[], help="key=value for lbm_set_tuning")
     ap.add_argument("--plane-pad", type=int, default=None,
                     help="doubles of padding between planes (default: lbm_default_plane_pad)")
+    ap.add_argument("--x2", type=int, default=1,
+                    help="1 (default): temporal blocking, two time steps per launch; 0: one step per launch")
+    ap.add_argument("--tb-rows", type=int, default=8, help="tile height of the two-step kernel")
     ap.add_argument("--force-halo", action="store_true",
                     help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv)")
     a = ap.parse_args()
@@ -122,8 +125,10 @@ def main():
 
     R, C = a.rows, a.cols
     prm = pylbm.BgkParams(a.omega, 0)
+    use_x2 = bool(a.x2) and C % 64 == 0 and R % a.tb_rows == 0 and R >= 4 * a.tb_rows
+    lib.set_tuning(b"tb_rows", a.tb_rows)
     ring = SlabRing(lib, R, C, rank, world, dev, periodic=True, plane_pad=a.plane_pad,
-                    force_ghost=a.force_halo)
+                    force_ghost=a.force_halo, depth=2 if use_x2 else 1)
     f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
     ring.load_precollision(f0, lambda dst, src, geom: lib.bgk_collide(
         _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring.stream_ptr()))
@@ -133,9 +138,27 @@ def main():
         lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
                                r0, r1, None, None, ring.stream_ptr())
 
-    ring.autotune(step_rows)          # picks the overlap schedule (no-op without ghost rows)
-    for _ in range(a.warmup):
-        ring.step(step_rows)
+    def step_rows_x2(dst, src, geom, bc, r0, r1):
+        lib.bgk_stream_collide_x2(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
+                                  r0, r1, ring.stream_ptr())
+
+    def advance(n):
+        """n time steps: pairs through the two-step kernel, a trailing odd one singly"""
+        if use_x2:
+            for _ in range(n // 2):
+                ring.step(step_rows_x2, edge_rows=a.tb_rows)
+            if n % 2:
+                ring.step(step_rows)
+        else:
+            for _ in range(n):
+                ring.step(step_rows)
+
+    # picks the overlap schedule (no-op without ghost rows)
+    if use_x2:
+        ring.autotune(step_rows_x2, edge_rows=a.tb_rows)
+    else:
+        ring.autotune(step_rows)
+    advance(a.warmup)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -143,8 +166,7 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    for _ in range(a.steps):
-        ring.step(step_rows)
+    advance(a.steps)
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -163,8 +185,11 @@ def main():
 
     if rank == 0:
         lups = R * C * world * a.steps / dt
-        kern_ms = dev_ms / a.steps                       # avg duration of one launch (1 per step at N=1)
-        achieved = R * C * BYTES_PER_LUP / (kern_ms * 1e-3) / 1e9
+        steps_per_launch = 2 if use_x2 else 1
+        launches = a.steps // 2 + a.steps % 2 if use_x2 else a.steps
+        kern_ms = dev_ms / launches                      # avg duration of one launch
+        alg_bytes = R * C * BYTES_PER_LUP * steps_per_launch   # algorithmic bytes one launch stands for
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "MLUPS (million lattice updates/sec), D2Q9 BGK periodic box, f64",
             "value": round(lups / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": a.steps,
@@ -172,19 +197,24 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{R}x{C} D2Q9 BGK periodic box per GPU, Taylor-Green init, "
-                                   f"fused collide+stream (pull, two SoA lattices), omega={a.omega}",
+                                   f"fused collide+stream (pull, two SoA lattices"
+                                   f"{', 2 time steps per launch through an LDS tile' if use_x2 else ''}), omega={a.omega}",
                        "rows_per_gpu": R, "cols": C, "global_rows": R * world,
                        "plane_pad_doubles": ring.plane - (R + 2 * ring.ghost) * C,
                        "parallelism": f"slab{world}" if world > 1 else "single",
-                       "halo": "1 row x 3 populations per side over RCCL send/recv" if ring.ghost else "none",
+                       "halo": ("none" if not ring.ghost else
+                                "9 rows of C doubles per side per 2 steps over RCCL send/recv" if ring.ghost == 2
+                                else "3 rows of C doubles per side per step over RCCL send/recv"),
                        "overlap_schedule": ring.schedule if ring.ghost else None,
                        "schedule_ms": getattr(ring, "autotune_ms", None)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 4),
-                         "traffic": None, "kernel": "k_stream_collide_v3<BgkModel,256,1,nt,nt>",
+                         "traffic": None, "kernel": (f"k_stream_collide_tb2<BgkModel,{a.tb_rows},512,nt>" if use_x2
+                                    else "k_stream_collide_v3<BgkModel,256,1,nt,nt>"),
                          "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": R * C * BYTES_PER_LUP},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "steps_per_launch": steps_per_launch},
             "check": {"total_mass": float(mass), "expected_mass": float(R * C * world)},
         }
         if world == 1 and not a.no_cpu_baseline:

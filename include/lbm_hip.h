@@ -83,7 +83,8 @@ typedef struct lbm_geom {
   int R;     /* rows owned by this block / slab (reference dim 0, pairs with c_x) */
   int C;     /* columns (reference dim 1, pairs with c_y) */
   int ghost; /* 0: planes are [R][C] and streaming wraps rows periodically inside the block
-                1: planes are [R+2][C]; rows -1 and R are ghost rows owned by the neighbours */
+                g = 1 or 2: planes are [R+2g][C]; rows -g..-1 and R..R+g-1 are ghost rows owned
+                by the neighbouring slabs (2 for the two-step launches) */
   long long plane_stride; /* doubles between consecutive population planes; 0 = dense
                              ((R + 2*ghost) * C).  Padding it off a power of two spreads the 18
                              concurrent streams of the fused step over the HBM channels. */
@@ -134,6 +135,14 @@ int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
 int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
                            const lbm_bc* bc, const lbm_bgk_params* prm, int row_begin,
                            int row_end, double* rho, double* u, lbm_stream_t s);
+/* Temporal blocking: p_new = TWO applications of the step above in one launch (an LDS tile keeps
+ * the intermediate lattice on chip: 72 instead of 144 HBM bytes per lattice update; every node
+ * undergoes the same arithmetic, results are bit-identical to two single steps).  Periodic or
+ * ghost-row edges only (ghost = 0 or 2; with 2 the caller keeps TWO ghost rows per side current),
+ * C % 64 == 0. */
+int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_bgk_params* prm, int row_begin,
+                              int row_end, lbm_stream_t s);
 /* f = stream(p) incl. boundary fix-ups == solver::advect + the driver's post-advect BCs. */
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s);
 

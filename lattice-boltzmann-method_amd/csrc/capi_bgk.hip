@@ -100,6 +100,16 @@ int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
   return LBM_OK;
 }
 
+int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_bgk_params* prm, int row_begin,
+                              int row_end, lbm_stream_t s) {
+  int rc = check_bgk("lbm_bgk_stream_collide_x2", prm);
+  if (rc) return rc;
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form};
+  return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, m, row_begin,
+                                  row_end, as_stream(s));
+}
+
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s) {
   int rc = validate_geom_bc("lbm_stream", g, bc);
   if (rc) return rc;

@@ -9,7 +9,7 @@ namespace lbm {
 inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc) {
   LBM_REQUIRE(g, "%s: NULL geometry", fn);
   LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
-  LBM_REQUIRE(g->ghost == 0 || g->ghost == 1, "%s: ghost=%d must be 0 or 1", fn, g->ghost);
+  LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 2, "%s: ghost=%d must be 0, 1 or 2", fn, g->ghost);
   LBM_REQUIRE(g->plane_stride == 0 || g->plane_stride >= (long long)(g->R + 2 * g->ghost) * g->C,
               "%s: plane_stride=%lld smaller than a plane", fn, g->plane_stride);
   if (bc) {
@@ -30,7 +30,7 @@ inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc)
     LBM_REQUIRE(!bc->pressure_rows || g->R >= 3, "%s: pressure rows need R >= 3", fn);
     if (g->ghost == 0)
       LBM_REQUIRE(bc->row_lo != LBM_EDGE_HALO && bc->row_hi != LBM_EDGE_HALO,
-                  "%s: HALO rows need ghost=1", fn);
+                  "%s: HALO rows need ghost rows (ghost >= 1)", fn);
   }
   return LBM_OK;
 }
@@ -112,6 +112,42 @@ int launch_stream_collide(const char* fn, double* pn, const double* po, const lb
     else LBM_KLAUNCH((k_edge_stream_collide<Model, false>), dim3((n_edge + 255) / 256), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
     LBM_CHECK_LAUNCH();
   }
+  return LBM_OK;
+}
+
+// p_new = two steps from p_old (temporal blocking); rows [row_begin, row_end), periodic / ghost edges
+template <class Model>
+int launch_stream_collide_x2(const char* fn, double* pn, const double* po, const lbm_geom* lg,
+                             const lbm_bc* lbc, const Model& m, int row_begin, int row_end,
+                             hipStream_t st) {
+  int rc = validate_geom_bc(fn, lg, lbc);
+  if (rc) return rc;
+  LBM_REQUIRE(pn && po && pn != po, "%s: NULL or aliased lattices", fn);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R,
+              "%s: row range [%d, %d) outside [0, %d)", fn, row_begin, row_end, lg->R);
+  const Bc bc = make_bc(lbc);
+  LBM_REQUIRE(!bc_needs_edge_pass(bc) && !bc.pressure_rows,
+              "%s: two-step launches support periodic / halo edges only", fn);
+  LBM_REQUIRE(lg->C % 64 == 0, "%s: C=%d must be a multiple of 64", fn, lg->C);
+  LBM_REQUIRE(lg->ghost == 0 || lg->ghost == 2, "%s: ghost=%d (two-step launches need 0 or 2 ghost rows)", fn, lg->ghost);
+  if (row_begin == row_end) return LBM_OK;
+  const Geom g = make_geom(*lg);
+  const int tiles_x = g.C / 64, nrows = row_end - row_begin;
+  const int tr = tuning("tb_rows", 8), block = tuning("tb_block", 512), nt = tuning("nt", 3) & 2;
+#define LBM_TB2(TRV, BV)                                                                          \
+  if (tr == TRV && block == BV) {                                                                 \
+    const long nblk = (long)tiles_x * ((nrows + TRV - 1) / TRV);                                  \
+    LBM_REQUIRE(nblk < (1L << 30), "%s: lattice too large for one launch", fn);                   \
+    if (nt) LBM_KLAUNCH((k_stream_collide_tb2<Model, TRV, BV, true>), dim3((unsigned)nblk), dim3(BV), 0, st, pn, po, g, m, row_begin, row_end, tiles_x); \
+    else LBM_KLAUNCH((k_stream_collide_tb2<Model, TRV, BV, false>), dim3((unsigned)nblk), dim3(BV), 0, st, pn, po, g, m, row_begin, row_end, tiles_x);   \
+  } else
+  LBM_TB2(4, 256) LBM_TB2(6, 256) LBM_TB2(8, 256) LBM_TB2(8, 512) LBM_TB2(12, 256) LBM_TB2(12, 512)
+  LBM_TB2(14, 512) LBM_TB2(16, 512) LBM_TB2(16, 1024) LBM_TB2(30, 1024) {
+    set_error("%s: no two-step instantiation for tb_rows=%d tb_block=%d", fn, tr, block);
+    return LBM_ERR_INVALID;
+  }
+#undef LBM_TB2
+  LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
 

@@ -3,17 +3,22 @@
 Semantics = the reference's block binding (test/decompose_domain.cpp:181-187): after a step
 the last row of block A must receive the populations moving towards -r ({3,6,7}) from the
 first row of block B and vice versa ({1,5,8}); the +-1 column shift of the diagonal ones is
-done by the pull kernel on the receiving side.  Here that is a one-row ghost layer per side:
-every rank sends 3 rows of C doubles to each neighbour per step (24*C bytes per side).
+done by the pull kernel on the receiving side.  Here that is a ghost layer per side:
 
-Layout: torch tensor [9, R+2, C] (plane row 0 = ghost row -1, rows 1..R owned, row R+1 = ghost
-row R), i.e. lbm_geom{R, C, ghost=1}; rows of one population are contiguous, so the halo rows
-are sent and received in place -- no pack/unpack kernels.  torch.distributed (backend "nccl" =
-RCCL over xGMI on the GPU box, "gloo" in the CPU tests) does the transport; compute is
-injected (`step_rows`) so the same ring logic is exercised on CPU by tests/test_slab_gloo.py.
+  depth 1 (one step per launch):  ghost row -1 needs {1,5,8} of the previous slab's last row,
+           ghost row R needs {3,6,7} of the next slab's first row: 3 rows of C doubles per side.
+  depth 2 (two steps per launch, temporal blocking): the first of the two fused steps is also
+           evaluated on ghost row -1 / R, so ghost row -1 needs {0,1,2,4,5,8} and ghost row -2
+           {1,5,8} (mirror image below): 9 rows of C doubles per side per TWO steps.
 
-Overlap: the two boundary rows are computed first; their halo messages then travel on the
-process group's stream while the interior rows are computed on the caller's stream.
+Layout: torch tensor viewed as [9, R+2g, C] (g ghost rows above and below the R owned rows),
+i.e. lbm_geom{R, C, ghost=g}; rows of one population are contiguous, so halo rows are sent and
+received in place -- no pack/unpack kernels.  torch.distributed (backend "nccl" = RCCL over xGMI
+on the GPU box, "gloo" in the CPU tests) does the transport; compute is injected (`step_rows`)
+so the same ring logic is exercised on CPU by tests/test_slab_gloo.py.
+
+Overlap: the edge rows are computed first; their halo messages then travel while the interior
+rows are computed on another stream.
 """
 import ctypes as ct
 
@@ -24,16 +29,23 @@ from . import EDGE_HALO, EDGE_PERIODIC, Bc, Geom
 
 TO_NEXT = (1, 5, 8)  # c_x = +1: leave through the last owned row
 TO_PREV = (3, 6, 7)  # c_x = -1: leave through the first owned row
+REST = (0, 2, 4)     # c_x = 0
+
+# (populations, owned row counted from the sending edge) per ghost depth; the receiver stores
+# them in the ghost row at the same distance from ITS edge.
+HALO_TO_NEXT = {1: [(TO_NEXT, 0)], 2: [(REST + TO_NEXT, 0), (TO_NEXT, 1)]}
+HALO_TO_PREV = {1: [(TO_PREV, 0)], 2: [(REST + TO_PREV, 0), (TO_PREV, 1)]}
 
 
 class SlabRing:
     def __init__(self, lib, R, C, rank, world, dev, periodic=True, bc=None, plane_pad=None,
-                 force_ghost=False):
+                 force_ghost=False, depth=1):
+        """depth: ghost rows per side when the lattice is split (1, or 2 for two-step launches)."""
         self.lib, self.R, self.C, self.rank, self.world, self.dev = lib, R, C, rank, world, dev
         self.periodic = periodic
         # force_ghost: keep the ghost rows (and the self-exchange) even on one rank -- lets a
         # single GPU exercise and time the halo path
-        self.ghost = 1 if (world > 1 or force_ghost) else 0
+        self.ghost = depth if (world > 1 or force_ghost) else 0
         rows = R + 2 * self.ghost
         # plane stride in doubles; a pad keeps the 9 planes off a common power-of-two stride
         if plane_pad is None:
@@ -71,19 +83,25 @@ class SlabRing:
         return self.owned().sum()
 
     def exchange(self, lat):
-        """Post the halo messages for `lat`; returns the outstanding requests."""
-        if not self.ghost:
+        """Post the halo messages for `lat`; returns the outstanding requests.  Sends are
+        issued (to next, to prev), receives (from prev, from next): with two ranks both
+        neighbours are the same peer and messages match in issue order."""
+        G, R = self.ghost, self.R
+        if not G:
             return []
-        R = self.R
         ops = []
-        if self.next_rank is not None:
-            ops += [dist.P2POp(dist.isend, lat[q, R], self.next_rank, tag=q) for q in TO_NEXT]
+        if self.next_rank is not None:   # my last rows -> their ghost rows above row 0
+            for pops, k in HALO_TO_NEXT[G]:
+                ops += [dist.P2POp(dist.isend, lat[q, G + R - 1 - k], self.next_rank, tag=10 * k + q) for q in pops]
+        if self.prev_rank is not None:   # my first rows -> their ghost rows below row R-1
+            for pops, k in HALO_TO_PREV[G]:
+                ops += [dist.P2POp(dist.isend, lat[q, G + k], self.prev_rank, tag=10 * k + q) for q in pops]
         if self.prev_rank is not None:
-            ops += [dist.P2POp(dist.isend, lat[q, 1], self.prev_rank, tag=q) for q in TO_PREV]
-        if self.prev_rank is not None:
-            ops += [dist.P2POp(dist.irecv, lat[q, 0], self.prev_rank, tag=q) for q in TO_NEXT]
+            for pops, k in HALO_TO_NEXT[G]:
+                ops += [dist.P2POp(dist.irecv, lat[q, G - 1 - k], self.prev_rank, tag=10 * k + q) for q in pops]
         if self.next_rank is not None:
-            ops += [dist.P2POp(dist.irecv, lat[q, R + 1], self.next_rank, tag=q) for q in TO_PREV]
+            for pops, k in HALO_TO_PREV[G]:
+                ops += [dist.P2POp(dist.irecv, lat[q, G + R + k], self.next_rank, tag=10 * k + q) for q in pops]
         return dist.batch_isend_irecv(ops) if ops else []
 
     # -- state ---------------------------------------------------------------------------
@@ -98,29 +116,33 @@ class SlabRing:
         for req in self.exchange(self.lat[self.cur]):
             req.wait()
 
-    def step(self, step_rows):
-        """One time step.  step_rows(dst, src, geom, bc, r0, r1) updates rows [r0, r1) on the
-        CURRENT torch stream (callers pass stream_ptr() at call time)."""
+    def step(self, step_rows, edge_rows=None):
+        """One launch-step over the slab (one time step, or two with a two-step `step_rows`).
+        step_rows(dst, src, geom, bc, r0, r1) updates rows [r0, r1) on the CURRENT torch stream
+        (callers pass stream_ptr() at call time).  edge_rows: how many rows at each end are
+        computed ahead of the exchange (default: the ghost depth; two-step kernels pass their
+        tile height)."""
         src, dst = self.lat[self.cur], self.lat[self.cur ^ 1]
         R = self.R
+        e = self.ghost if edge_rows is None else edge_rows
         if not self.ghost:
             step_rows(dst, src, self.geom, self.bc, 0, R)
         elif self.dev.type != "cuda":
-            step_rows(dst, src, self.geom, self.bc, 0, 1)
-            step_rows(dst, src, self.geom, self.bc, R - 1, R)
+            step_rows(dst, src, self.geom, self.bc, 0, e)
+            step_rows(dst, src, self.geom, self.bc, R - e, R)
             reqs = self.exchange(dst)
-            step_rows(dst, src, self.geom, self.bc, 1, R - 1)
+            step_rows(dst, src, self.geom, self.bc, e, R - e)
             for req in reqs:
                 req.wait()
         else:
-            # Overlap schedule.  Stream E ("edge"): the two boundary rows, then the halo
-            # messages.  Stream I: the interior rows, enqueued BEFORE the exchange is posted so
-            # that neither the host-side cost of posting 12 messages nor RCCL's kernel leaves
-            # the GPU idle (measured: a 134 us bubble per step otherwise).  Whether RCCL's
-            # internal stream shares a hardware queue with torch's current stream or with our
-            # side stream is not ours to choose, so both role assignments exist
-            # (self.schedule 0: I = current, E = side; 1: I = side, E = current) and
-            # autotune() picks the faster one during warm-up.
+            # Overlap schedule.  Stream E ("edge"): the boundary rows, then the halo messages.
+            # Stream I: the interior rows, enqueued BEFORE the exchange is posted so that
+            # neither the host-side cost of posting the messages nor RCCL's kernel leaves the
+            # GPU idle (measured: a 134 us bubble per step otherwise).  Whether RCCL's internal
+            # stream shares a hardware queue with torch's current stream or with our side
+            # stream is not ours to choose, so both role assignments exist (self.schedule
+            # 0: I = current, E = side; 1: I = side, E = current) and autotune() picks the
+            # faster one during warm-up.
             cur = torch.cuda.current_stream(self.dev)
             if self.side is None:
                 lo, hi = torch.cuda.Stream.priority_range()
@@ -129,30 +151,31 @@ class SlabRing:
             edge.wait_stream(inner)         # previous step (other lattice) fully done
             inner.wait_stream(edge)
             with torch.cuda.stream(edge):
-                step_rows(dst, src, self.geom, self.bc, 0, 1)
-                step_rows(dst, src, self.geom, self.bc, R - 1, R)
+                step_rows(dst, src, self.geom, self.bc, 0, e)
+                step_rows(dst, src, self.geom, self.bc, R - e, R)
             with torch.cuda.stream(inner):
-                step_rows(dst, src, self.geom, self.bc, 1, R - 1)
+                step_rows(dst, src, self.geom, self.bc, e, R - e)
             with torch.cuda.stream(edge):
                 for req in self.exchange(dst):
                     req.wait()              # stream-level wait: edge now trails the transfers
             cur.wait_stream(self.side)      # callers synchronise on the current stream
         self.cur ^= 1
 
-    def autotune(self, step_rows, steps=6):
+    def autotune(self, step_rows, steps=6, edge_rows=None):
         """Time both overlap schedules (GPU, ghost rows only) and keep the faster; all ranks
-        agree through an all-reduce(MAX) of the timings.  Advances the state by 2*steps+2."""
+        agree through an all-reduce(MAX) of the timings.  Advances the state by 2*steps+2
+        launch-steps."""
         if not self.ghost or self.dev.type != "cuda":
             return self.schedule
         times = []
         for sched in (0, 1):
             self.schedule = sched
-            self.step(step_rows)            # settle streams / lazy inits
+            self.step(step_rows, edge_rows)  # settle streams / lazy inits
             torch.cuda.synchronize(self.dev)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(steps):
-                self.step(step_rows)
+                self.step(step_rows, edge_rows)
             e1.record()
             torch.cuda.synchronize(self.dev)
             times.append(e0.elapsed_time(e1))
@@ -160,5 +183,5 @@ class SlabRing:
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         self.schedule = int(t[1] < t[0])
-        self.autotune_ms = [float(x) / steps for x in t]
+        self.autotune_ms = [float(x) / max(steps, 1) for x in t]
         return self.schedule

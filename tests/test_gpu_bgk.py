@@ -303,5 +303,104 @@ def test_slab_ring_rccl_self_exchange(lib, oracle):
         lib.stream(_ptr(out), _ptr(p), ct.byref(pylbm.Geom(R, C, 0)), None, None)
         got = download_aos(lib, out)
         assert bits_equal(got, want), ulp_diff(got, want)
+
+        # depth 2: two time steps per launch, 9 halo rows per side per launch
+        want2, _, _ = oracle.bgk_periodic_steps(f0, 1.1, 1 + 2 * 4)
+        ring2 = SlabRing(lib, R, C, 0, 1, d, periodic=True, force_ghost=True, depth=2)
+        assert ring2.ghost == 2
+        ring2.load_precollision(f0d, lambda dst, src, geom: lib.bgk_collide(
+            _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring2.stream_ptr()))
+
+        def step_rows_x2(dst, src, geom, bc, r0, r1):
+            lib.bgk_stream_collide_x2(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc),
+                                      ct.byref(prm), r0, r1, ring2.stream_ptr())
+        lib.set_tuning(b"tb_rows", 8)
+        ring2.autotune(step_rows_x2, steps=0, edge_rows=8)   # both schedules once: 2 launches
+        for _ in range(2):
+            ring2.step(step_rows_x2, edge_rows=8)
+        torch.cuda.synchronize()
+        p = ring2.owned().contiguous()
+        lib.stream(_ptr(out), _ptr(p), ct.byref(pylbm.Geom(R, C, 0)), None, None)
+        got = download_aos(lib, out)
+        assert bits_equal(got, want2), ulp_diff(got, want2)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("R,C", [(40, 128), (37, 64), (5, 192), (130, 256)])
+def test_two_step_temporal_blocking_bit_identical(lib, oracle, R, C):
+    """lbm_bgk_stream_collide_x2 (two steps per launch through an LDS tile) == two single
+    steps == oracle, bitwise, for every tile shape; rows not a multiple of the tile included."""
+    f0 = random_state(oracle, R, C, seed=R + C)
+    n_pairs = 3
+    want, _, _ = oracle.bgk_periodic_steps(f0, 1.5, 1 + 2 * n_pairs)
+    prm = pylbm.BgkParams(1.5, 0)
+    g = pylbm.Geom(R, C, 0)
+    f0d = upload_soa(lib, f0)
+    for tr, blk in [(4, 256), (6, 256), (8, 256), (8, 512), (12, 256), (12, 512), (14, 512),
+                    (16, 512), (16, 1024), (30, 1024)]:
+        lib.set_tuning(b"tb_rows", tr)
+        lib.set_tuning(b"tb_block", blk)
+        a = torch.empty((9, R, C), dtype=torch.float64, device=dev())
+        b = torch.empty_like(a)
+        lib.bgk_collide(_ptr(a), _ptr(f0d), ct.byref(g), None, ct.byref(prm), None, None, None)
+        for _ in range(n_pairs):
+            lib.bgk_stream_collide_x2(_ptr(b), _ptr(a), ct.byref(g), None, ct.byref(prm), 0, R, None)
+            a, b = b, a
+        out = torch.empty_like(a)
+        lib.stream(_ptr(out), _ptr(a), ct.byref(g), None, None)
+        got = download_aos(lib, out)
+        assert bits_equal(got, want), (tr, blk, ulp_diff(got, want))
+    lib.set_tuning(b"tb_rows", -1)
+    lib.set_tuning(b"tb_block", -1)
+
+
+def test_two_slabs_two_step_launches_equal_single_block(lib, oracle):
+    """Temporal blocking across a seam: 2 slabs with TWO ghost rows emulated on one GPU, halo per
+    pair of steps = the 9 rows per side SlabRing(depth=2) sends, edge tiles and interior tiles
+    launched separately.  Must equal the single periodic block bitwise."""
+    from pylbm.slab import HALO_TO_NEXT, HALO_TO_PREV
+    Rg, C, pairs, TR = 96, 128, 3, 8
+    R, G = Rg // 2, 2
+    f0 = random_state(oracle, Rg, C, seed=78)
+    want, _, _ = oracle.bgk_periodic_steps(f0, 1.4, 1 + 2 * pairs)
+    prm = pylbm.BgkParams(1.4, 0)
+    flat = pylbm.Geom(Rg, C, 0)
+    p0 = torch.empty((9, Rg, C), dtype=torch.float64, device=dev())
+    f0d = upload_soa(lib, f0)
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(flat), None, ct.byref(prm), None, None, None)
+    torch.cuda.synchronize()
+    geom = pylbm.Geom(R, C, G)
+    bc = pylbm.Bc.periodic()
+    bc.row_lo = bc.row_hi = pylbm.EDGE_HALO
+    lat = [[torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=dev()) for _ in range(2)] for _ in range(2)]
+
+    def halo(cur):
+        for s in range(2):
+            o = 1 - s
+            for pops, k in HALO_TO_NEXT[2]:
+                for q in pops:
+                    lat[o][cur][q, G - 1 - k] = lat[s][cur][q, G + R - 1 - k]
+            for pops, k in HALO_TO_PREV[2]:
+                for q in pops:
+                    lat[o][cur][q, G + R + k] = lat[s][cur][q, G + k]
+
+    for s in range(2):
+        lat[s][0][:, G:G + R] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    lib.set_tuning(b"tb_rows", TR)
+    cur = 0
+    for _ in range(pairs):
+        for s in range(2):
+            src, dst = lat[s][cur], lat[s][cur ^ 1]
+            for r0, r1 in ((0, TR), (R - TR, R), (TR, R - TR)):
+                lib.bgk_stream_collide_x2(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc),
+                                          ct.byref(prm), r0, r1, None)
+        torch.cuda.synchronize()
+        cur ^= 1
+        halo(cur)
+    p = torch.cat([lat[0][cur][:, G:G + R], lat[1][cur][:, G:G + R]], dim=1).contiguous()
+    out = torch.empty_like(p)
+    lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
+    got = download_aos(lib, out)
+    assert bits_equal(got, want), ulp_diff(got, want)

@@ -49,17 +49,47 @@ def np_step_rows(dst, src, geom, bc, r0, r1):
     d[:, g + r0: g + r1, :] = np_collide(f)
 
 
-def worker(rank, world, port, R, C, steps, f0_path, out_path):
+def np_step_rows_x2(dst, src, geom, bc, r0, r1):
+    """two fused steps on rows [r0, r1) of the [9, R+4, C] ghost-2 layout: the first step is
+    evaluated on rows [r0-1, r1+1) (it reaches one row into the ghost layer)."""
+    s, d = src.numpy(), dst.numpy()
+    g = geom.ghost
+    assert g == 2
+    lo, hi = r0 - 1, r1 + 1
+    f = np.empty((9, hi - lo, geom.C))
+    for q in range(9):
+        f[q] = np.roll(s[q, g + lo - CX[q]: g + hi - CX[q], :], CY[q], axis=1)
+    p1 = np_collide(f)                       # rows lo..hi-1  (index 0 <-> row lo)
+    f2 = np.empty((9, r1 - r0, geom.C))
+    for q in range(9):
+        f2[q] = np.roll(p1[q, 1 - CX[q]: 1 - CX[q] + (r1 - r0), :], CY[q], axis=1)
+    d[:, g + r0: g + r1, :] = np_collide(f2)
+
+
+def worker(rank, world, port, R, C, steps, f0_path, out_path, depth=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pylbm.slab import SlabRing
     f0 = np.load(f0_path)  # global AoS [R*world, C, 9]
     mine = np.ascontiguousarray(np.moveaxis(f0[rank * R:(rank + 1) * R], -1, 0))  # SoA [9,R,C]
-    ring = SlabRing(None, R, C, rank, world, torch.device("cpu"), periodic=True, plane_pad=7)
+    ring = SlabRing(None, R, C, rank, world, torch.device("cpu"), periodic=True, plane_pad=7, depth=depth)
     ring.load_precollision(torch.from_numpy(mine), lambda dst, src, geom: dst.copy_(
         torch.from_numpy(np_collide(src.numpy()))))
-    for _ in range(steps - 1):  # n driver iterations = 1 collide + (n-1) fused steps
-        ring.step(np_step_rows)
+    if depth == 1:
+        for _ in range(steps - 1):  # n driver iterations = 1 collide + (n-1) fused steps
+            ring.step(np_step_rows)
+    else:                           # pairs through the two-step path, a trailing odd one singly
+        def single(dst, src, geom, bc, r0, r1):   # one step on the ghost-2 layout
+            s_, d_ = src.numpy(), dst.numpy()
+            f = np.empty((9, r1 - r0, geom.C))
+            for q in range(9):
+                f[q] = np.roll(s_[q, 2 + r0 - CX[q]: 2 + r1 - CX[q], :], CY[q], axis=1)
+            d_[:, 2 + r0: 2 + r1, :] = np_collide(f)
+        n = steps - 1
+        for _ in range(n // 2):
+            ring.step(np_step_rows_x2, edge_rows=2)
+        if n % 2:
+            ring.step(single)
     parts = [torch.empty_like(ring.owned().contiguous()) for _ in range(world)]
     dist.all_gather(parts, ring.owned().contiguous())
     if rank == 0:
@@ -68,17 +98,17 @@ def worker(rank, world, port, R, C, steps, f0_path, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slab_ring_equals_single_box(world, tmp_path, oracle):
-    R, C, steps = 6, 16, 9
+@pytest.mark.parametrize("world,depth,steps", [(2, 1, 9), (3, 1, 9), (2, 2, 9), (3, 2, 10)])
+def test_slab_ring_equals_single_box(world, depth, steps, tmp_path, oracle):
+    R, C = 6, 16
     rng = np.random.default_rng(world)
     rho = 1 + 0.02 * rng.standard_normal((R * world, C))
     u = 0.05 * rng.standard_normal((R * world, C, 2))
     f0 = oracle.equilibrium(u, rho) * (1 + 0.01 * rng.standard_normal((R * world, C, 9)))
     f0_path, out_path = str(tmp_path / "f0.npy"), str(tmp_path / "p.npy")
     np.save(f0_path, f0)
-    port = 29500 + (os.getpid() % 2000) + world
-    mp.start_processes(worker, args=(world, port, R, C, steps, f0_path, out_path), nprocs=world,
+    port = 29500 + (os.getpid() % 2000) + 10 * world + depth
+    mp.start_processes(worker, args=(world, port, R, C, steps, f0_path, out_path, depth), nprocs=world,
                        join=True, start_method="spawn")
     p_global = np.moveaxis(np.load(out_path), 0, -1)          # AoS post-collision populations
     got = oracle.advect(np.ascontiguousarray(p_global))       # f_adve after `steps` iterations
