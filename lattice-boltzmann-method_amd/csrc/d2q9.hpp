@@ -374,10 +374,22 @@ __global__ __launch_bounds__(BLOCK) void k_stream_collide_v3(
 template <class Model, int TR, int BLOCK, bool NT_STORE>
 __global__ __launch_bounds__(BLOCK) void k_stream_collide_tb2(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
-    int row_end, int tiles_x) {
+    int row_end, int tiles_x, int tiles_y, int order) {
   constexpr int TC = 64, LR = TR + 2, LC = TC + 2;
   __shared__ double s[Q][LR][LC];
-  const int r0 = row_begin + (blockIdx.x / tiles_x) * TR, c0 = (blockIdx.x % tiles_x) * TC;
+  int tx, ty;
+  if (order == 1) {
+    // XCD-aware: workgroups are dealt round-robin over the 8 XCDs; XCD k owns tile columns
+    // tx = k (mod 8) and walks DOWN each of them, so vertically adjacent tiles -- which share
+    // two halo rows of every population -- run back to back on one L2.  (tiles_x % 8 == 0)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    tx = (j / tiles_y) * 8 + xcd;
+    ty = j % tiles_y;
+  } else {
+    tx = blockIdx.x % tiles_x;
+    ty = blockIdx.x / tiles_x;
+  }
+  const int r0 = row_begin + ty * TR, c0 = tx * TC;
   for (int i = threadIdx.x; i < LR * LC; i += BLOCK) {
     const int lr = i / LC, lc = i - lr * LC;
     const int r = wrap_row(g, r0 + lr - 1), c = wrap_col(g, c0 + lc - 1);

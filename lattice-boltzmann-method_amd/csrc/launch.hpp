@@ -134,12 +134,14 @@ int launch_stream_collide_x2(const char* fn, double* pn, const double* po, const
   const Geom g = make_geom(*lg);
   const int tiles_x = g.C / 64, nrows = row_end - row_begin;
   const int tr = tuning("tb_rows", 8), block = tuning("tb_block", 512), nt = tuning("nt", 3) & 2;
+  const int order = (tiles_x % 8 == 0) ? tuning("tb_order", 0) : 0;
 #define LBM_TB2(TRV, BV)                                                                          \
   if (tr == TRV && block == BV) {                                                                 \
-    const long nblk = (long)tiles_x * ((nrows + TRV - 1) / TRV);                                  \
+    const int tiles_y = (nrows + TRV - 1) / TRV;                                                  \
+    const long nblk = (long)tiles_x * tiles_y;                                                    \
     LBM_REQUIRE(nblk < (1L << 30), "%s: lattice too large for one launch", fn);                   \
-    if (nt) LBM_KLAUNCH((k_stream_collide_tb2<Model, TRV, BV, true>), dim3((unsigned)nblk), dim3(BV), 0, st, pn, po, g, m, row_begin, row_end, tiles_x); \
-    else LBM_KLAUNCH((k_stream_collide_tb2<Model, TRV, BV, false>), dim3((unsigned)nblk), dim3(BV), 0, st, pn, po, g, m, row_begin, row_end, tiles_x);   \
+    if (nt) LBM_KLAUNCH((k_stream_collide_tb2<Model, TRV, BV, true>), dim3((unsigned)nblk), dim3(BV), 0, st, pn, po, g, m, row_begin, row_end, tiles_x, tiles_y, order); \
+    else LBM_KLAUNCH((k_stream_collide_tb2<Model, TRV, BV, false>), dim3((unsigned)nblk), dim3(BV), 0, st, pn, po, g, m, row_begin, row_end, tiles_x, tiles_y, order);   \
   } else
   LBM_TB2(4, 256) LBM_TB2(6, 256) LBM_TB2(8, 256) LBM_TB2(8, 512) LBM_TB2(12, 256) LBM_TB2(12, 512)
   LBM_TB2(14, 512) LBM_TB2(16, 512) LBM_TB2(16, 1024) LBM_TB2(30, 1024) {
