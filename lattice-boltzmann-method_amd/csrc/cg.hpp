@@ -146,11 +146,14 @@ __global__ __launch_bounds__(256) void k_cg_stream_moments(
 }
 
 // ---- pass B ---------------------------------------------------------------------------------
+#ifndef LBM_CG_WAVES
+#define LBM_CG_WAVES 1  // waves per SIMD the collide kernel is register-budgeted for (measured)
+#endif
 constexpr int CG_TR = 8, CG_TC = 32;               // tile of nodes per 256-thread block
 constexpr int CG_LR = CG_TR + 4, CG_LC = CG_TC + 4;  // with the +-2 stencil halo
 
 template <bool FROM_POST, bool WITH_FIELDS>
-__global__ __launch_bounds__(256) void k_cg_collide(
+__global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
     double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
     const double* __restrict__ in_b, const double* __restrict__ rho_r,
     const double* __restrict__ rho_b, const double* __restrict__ u, Geom g, Bc bc, CgConsts cc,
@@ -206,59 +209,67 @@ __global__ __launch_bounds__(256) void k_cg_collide(
   const double s_nu = cg_snu(cc, psi);
   const double S[Q] = {0.0, 1.25, 1.14, 0.0, 1.6, 0.0, 1.6, s_nu, s_nu};  // :384-386, :227-231
 
-  double f[2][Q], om1[2][Q];
-  if (FROM_POST) {
-    gather_bc(f[0], in_r, g, bc, r, c);
-    gather_bc(f[1], in_b, g, bc, r, c);
-  } else {
-    const long lo = g.at(r, c);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      f[0][q] = in_r[q * g.plane + lo];
-      f[1][q] = in_b[q * g.plane + lo];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    double feq[Q], m[Q];
-    cg_feq(feq, k ? rb : rr, cc.k[k], ux, uy);  // :431-432
-#pragma unroll
-    for (int a = 0; a < Q; ++a) {                // eval_mrt_operator :249-261
-      double s = 0.0;
-#pragma unroll
-      for (int q = 0; q < Q; ++q) s += cg_M(a, q) * (feq[q] - f[k][q]);
-      double Ck = 0.0;                           // update_C :320-336
-      if (a == 1) Ck = 3.0 * (1.0 - 0.5 * 1.25) * (dxq[k] + dyq[k]);
-      if (a == 7) Ck = (1.0 - 0.5 * s_nu) * (dxq[k] - dyq[k]);
-      m[a] = S[a] * s + Ck;
-    }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      double s = 0.0;
-#pragma unroll
-      for (int a = 0; a < Q; ++a) s += ((1.0 / 36.0) * cg_Mi36(q, a)) * m[a];
-      om1[k][q] = s;
-    }
-  }
   const double gnorm = sqrt(gx * gx + gy * gy);  // :444-447
   const double A = 4.5 * cc.sigma * s_nu;        // :450
   const long lo = g.at(r, c);
+  // Omega2 (perturbation, identical for both colours) first, then total_f accumulated colour by
+  // colour in the driver's left-to-right order (:455)
+  //   total_f = r.adv_f + r.omega1 + r.omega2 + b.adv_f + b.omega1 + b.omega2
+  // so that only ONE colour's populations are live at a time (register pressure).
+  double om2[Q], tot[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const double gE = gx * (double)icx(q) + gy * (double)icy(q);
     const double t1 = gE / (1e-20 + gnorm);
     const double xi = 0.5 * gnorm * (wq(q) * (t1 * t1) - cg_B(q));  // eval_xi :290-300
-    const double om2 = A * xi;                                        // :263-273
+    om2[q] = A * xi;                                                  // :263-273
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double f[Q], m[Q];
+    if (FROM_POST) {
+      gather_bc(f, k ? in_b : in_r, g, bc, r, c);
+    } else {
+      const double* in = k ? in_b : in_r;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = in[q * g.plane + lo];
+    }
+    {
+      double d[Q];
+      cg_feq(d, k ? rb : rr, cc.k[k], ux, uy);  // :431-432
+#pragma unroll
+      for (int q = 0; q < Q; ++q) d[q] = d[q] - f[q];
+#pragma unroll
+      for (int a = 0; a < Q; ++a) {              // eval_mrt_operator :249-261
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) s += cg_M(a, q) * d[q];
+        double Ck = 0.0;                         // update_C :320-336
+        if (a == 1) Ck = 3.0 * (1.0 - 0.5 * 1.25) * (dxq[k] + dyq[k]);
+        if (a == 7) Ck = (1.0 - 0.5 * s_nu) * (dxq[k] - dyq[k]);
+        m[a] = S[a] * s + Ck;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      double om1 = 0.0;
+#pragma unroll
+      for (int a = 0; a < Q; ++a) om1 += ((1.0 / 36.0) * cg_Mi36(q, a)) * m[a];
+      if (k == 0) tot[q] = f[q] + om1 + om2[q];
+      else tot[q] = tot[q] + f[q] + om1 + om2[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
     const double gU = gx * cc.unitx[q] + gy * cc.unity[q];
     const double kappa = (rr * rb * gU * (rr * cc.k[0].phi[q] + rb * cc.k[1].phi[q])) /
                          ((rt * rt) * (1e-20 + gnorm));               // eval_kappa :302-318
-    const double tot = f[0][q] + om1[0][q] + om2 + f[1][q] + om1[1][q] + om2;  // :455
     const double cu = ux * (double)icx(q) + uy * (double)icy(q);
     const double FgE = cc.g * (double)icx(q) + 0.0 * (double)icy(q);
     const double uFg = ux * cc.g + uy * 0.0;
     const double Fq = (1 - 0.5 * s_nu) * ((3.0 + 9.0 * cu) * FgE - 3.0 * uFg) * wq(q);  // :460-462
-    pn_r[q * g.plane + lo] = (rr * tot / rt + cc.k[0].beta * kappa) + Fq;  // :275-288, :463
-    pn_b[q * g.plane + lo] = (rb * tot / rt + cc.k[1].beta * kappa) + Fq;  // :464
+    pn_r[q * g.plane + lo] = (rr * tot[q] / rt + cc.k[0].beta * kappa) + Fq;  // :275-288, :463
+    pn_b[q * g.plane + lo] = (rb * tot[q] / rt + cc.k[1].beta * kappa) + Fq;  // :464
   }
   if (WITH_FIELDS) {
     psi_out[o] = psi;

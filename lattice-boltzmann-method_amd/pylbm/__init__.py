@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 REPO = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "liblbm_hip.so")
+LIB_PATH = os.environ.get("LBM_HIP_LIB", os.path.join(PKG_DIR, "lib", "liblbm_hip.so"))
 HEADER = os.path.join(REPO, "include", "lbm_hip.h")
 
 EDGE_PERIODIC, EDGE_HALO, EDGE_BOUNCE_BACK, EDGE_SPECULAR, EDGE_ABB_VELOCITY, EDGE_WRAP_NOSHIFT = range(6)
