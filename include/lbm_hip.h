@@ -83,8 +83,9 @@ typedef struct lbm_geom {
   int R;     /* rows owned by this block / slab (reference dim 0, pairs with c_x) */
   int C;     /* columns (reference dim 1, pairs with c_y) */
   int ghost; /* 0: planes are [R][C] and streaming wraps rows periodically inside the block
-                g = 1 or 2: planes are [R+2g][C]; rows -g..-1 and R..R+g-1 are ghost rows owned
-                by the neighbouring slabs (2 for the two-step launches) */
+                g = 1, 2 or 3: planes are [R+2g][C]; rows -g..-1 and R..R+g-1 are ghost rows
+                owned by the neighbouring slabs (1: one step per launch; 2: two-step launches;
+                3: the colour-gradient step) */
   long long plane_stride; /* doubles between consecutive population planes; 0 = dense
                              ((R + 2*ghost) * C).  Padding it off a power of two spreads the 18
                              concurrent streams of the fused step over the HBM channels. */
@@ -197,6 +198,11 @@ int lbm_cg_collide(double* p_r, double* p_b, const double* f_r, const double* f_
                    const double* rho_r, const double* rho_b, const double* u, const lbm_geom* g,
                    const lbm_bc* bc, const lbm_cg_params* prm, double* psi /* may be NULL */,
                    double* s_nu /* may be NULL */, lbm_stream_t s);
+/* Slabs: populations with lbm_geom.ghost = 3; the macroscopic fields then carry 2 ghost rows per
+ * side (rho[(R+4)][C], u[2][(R+4)][C], row r at (r+2)*C): pass A recomputes them on rows -2..R+1
+ * from the populations' ghost rows, so ONE population exchange per step (3 rows, both colours)
+ * feeds both the streaming and the 5x5 stencils; the stencils clamp at GLOBAL edges only
+ * (row_lo/row_hi != LBM_EDGE_HALO).  Single block: ghost = 0, fields [R][C]. */
 /* pass A: :466-477 fused -- advect + BCs of both colours, rho_k, u incl. the Fg/(2 rho) shift */
 int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double* p_r,
                           const double* p_b, const lbm_geom* g, const lbm_bc* bc,
@@ -205,7 +211,7 @@ int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double*
 int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
                           const double* rho_r, const double* rho_b, const double* u,
                           const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm,
-                          double* psi, double* s_nu, lbm_stream_t s);
+                          int row_begin, int row_end, double* psi, double* s_nu, lbm_stream_t s);
 /* driver loop context (single block); host arrays in the reference's shapes */
 typedef struct lbm_cg_solver lbm_cg_solver;
 int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* bc /* NULL = default */,
@@ -231,6 +237,11 @@ typedef struct lbm_ibm lbm_ibm;
  * m_max: ibm.hpp:25 default 5 (m_max - 1 forcing iterations); X, Y: lattice size */
 int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
                    int X, int Y);
+/* the same for a row slab that owns the whole ROI: X = rows of the slab, which start at global
+ * row `row_offset`; x stays in GLOBAL coordinates (weights identical to the single-block ones),
+ * lbm_ibm_roi and the u/rho/lattice arguments of the calls below are slab-local */
+int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
+                        int X, int Y, int row_offset);
 int lbm_ibm_destroy(lbm_ibm* ib);
 /* region of interest rows [r0, r1), columns [c0, c1)  (ibm.cpp:104-156) */
 int lbm_ibm_roi(const lbm_ibm* ib, int* r0, int* r1, int* c0, int* c1);

@@ -45,7 +45,7 @@ static int check_cg(const char* fn, const lbm_geom* g, const lbm_bc* bc, const l
   int rc = validate_geom_bc(fn, g, bc);
   if (rc) return rc;
   LBM_REQUIRE(p, "%s: NULL params", fn);
-  LBM_REQUIRE(g->ghost == 0, "%s: single block only in this version (ghost=0)", fn);
+  LBM_REQUIRE(g->ghost == 0 || g->ghost == 3, "%s: ghost=%d (the two-phase step needs 0 or 3 ghost rows)", fn, g->ghost);
   LBM_REQUIRE(p->red.rho_0 > 0 && p->blue.rho_0 > 0 && p->delta > 0, "%s: bad colour parameters", fn);
   LBM_REQUIRE(p->red.alpha < 1.0 && p->blue.alpha < 1.0, "%s: alpha must be < 1", fn);
   return LBM_OK;
@@ -54,18 +54,22 @@ static int check_cg(const char* fn, const lbm_geom* g, const lbm_bc* bc, const l
 static int launch_cg_collide(bool from_post, double* pn_r, double* pn_b, const double* in_r,
                              const double* in_b, const double* rho_r, const double* rho_b,
                              const double* u, const lbm_geom* lg, const lbm_bc* lbc,
-                             const lbm_cg_params* prm, double* psi, double* snu, hipStream_t st) {
+                             const lbm_cg_params* prm, double* psi, double* snu, int row_begin,
+                             int row_end, hipStream_t st) {
   const Geom g = make_geom(*lg);
   const Bc bc = make_bc(lbc);
   const CgConsts cc = make_cg_consts(*prm);
-  const int tiles = ((g.R + CG_TR - 1) / CG_TR) * ((g.C + CG_TC - 1) / CG_TC);
+  const MacroIdx mi = make_macro_idx(g);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= g.R, "lbm_cg: row range [%d, %d) outside [0, %d)", row_begin, row_end, g.R);
+  if (row_begin == row_end) return LBM_OK;
+  const int tiles = ((row_end - row_begin + CG_TR - 1) / CG_TR) * ((g.C + CG_TC - 1) / CG_TC);
   const bool fields = psi != nullptr;
   if (from_post) {
-    if (fields) LBM_KLAUNCH((k_cg_collide<true, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
-    else LBM_KLAUNCH((k_cg_collide<true, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
+    if (fields) LBM_KLAUNCH((k_cg_collide<true, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu, mi, row_begin, row_end);
+    else LBM_KLAUNCH((k_cg_collide<true, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu, mi, row_begin, row_end);
   } else {
-    if (fields) LBM_KLAUNCH((k_cg_collide<false, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
-    else LBM_KLAUNCH((k_cg_collide<false, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu);
+    if (fields) LBM_KLAUNCH((k_cg_collide<false, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu, mi, row_begin, row_end);
+    else LBM_KLAUNCH((k_cg_collide<false, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu, mi, row_begin, row_end);
   }
   LBM_CHECK_LAUNCH();
   return LBM_OK;
@@ -113,7 +117,7 @@ int lbm_cg_collide(double* p_r, double* p_b, const double* f_r, const double* f_
   if (rc) return rc;
   LBM_REQUIRE(p_r && p_b && f_r && f_b && rho_r && rho_b && u, "lbm_cg_collide: NULL pointer");
   LBM_REQUIRE((psi == nullptr) == (snu == nullptr), "lbm_cg_collide: psi and s_nu go together");
-  return launch_cg_collide(false, p_r, p_b, f_r, f_b, rho_r, rho_b, u, g, bc, prm, psi, snu, as_stream(s));
+  return launch_cg_collide(false, p_r, p_b, f_r, f_b, rho_r, rho_b, u, g, bc, prm, psi, snu, 0, g->R, as_stream(s));
 }
 
 int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double* p_r,
@@ -123,9 +127,11 @@ int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double*
   if (rc) return rc;
   LBM_REQUIRE(rho_r && rho_b && u && p_r && p_b, "lbm_cg_stream_moments: NULL pointer");
   const Geom gg = make_geom(*g);
-  const long n = (long)gg.R * gg.C;
+  const Bc bb = make_bc(bc);
+  const int lo = cg_row_lo(gg, bb), hi = cg_row_hi(gg, bb) + 1;  // incl. the macro ghost rows of a slab
+  const long n = (long)(hi - lo) * gg.C;
   LBM_KLAUNCH(k_cg_stream_moments, dim3(capped_grid((n + 255) / 256, 8192)), dim3(256), 0, as_stream(s),
-              rho_r, rho_b, u, p_r, p_b, gg, make_bc(bc), prm->gravity);
+              rho_r, rho_b, u, p_r, p_b, gg, bb, prm->gravity, make_macro_idx(gg), lo, hi);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
@@ -133,13 +139,13 @@ int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double*
 int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
                           const double* rho_r, const double* rho_b, const double* u,
                           const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm,
-                          double* psi, double* snu, lbm_stream_t s) {
+                          int row_begin, int row_end, double* psi, double* snu, lbm_stream_t s) {
   int rc = check_cg("lbm_cg_stream_collide", g, bc, prm);
   if (rc) return rc;
   LBM_REQUIRE(pn_r && pn_b && p_r && p_b && rho_r && rho_b && u, "lbm_cg_stream_collide: NULL pointer");
   LBM_REQUIRE(pn_r != p_r && pn_b != p_b, "lbm_cg_stream_collide: aliased lattices");
   LBM_REQUIRE((psi == nullptr) == (snu == nullptr), "lbm_cg_stream_collide: psi and s_nu go together");
-  return launch_cg_collide(true, pn_r, pn_b, p_r, p_b, rho_r, rho_b, u, g, bc, prm, psi, snu, as_stream(s));
+  return launch_cg_collide(true, pn_r, pn_b, p_r, p_b, rho_r, rho_b, u, g, bc, prm, psi, snu, row_begin, row_end, as_stream(s));
 }
 
 }  // extern "C"
@@ -241,7 +247,7 @@ int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps) {
                                  &sv->prm, sv->st);
       if (rc) return rc;
       rc = lbm_cg_stream_collide(dst[0], dst[1], src[0], src[1], sv->rho_r, sv->rho_b, sv->u,
-                                 &sv->g, &sv->bc, &sv->prm, sv->psi, sv->snu, sv->st);
+                                 &sv->g, &sv->bc, &sv->prm, 0, sv->g.R, sv->psi, sv->snu, sv->st);
     }
     if (rc) return rc;
     sv->cur ^= 1;

@@ -150,6 +150,11 @@ extern "C" {
 
 int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
                    int X, int Y) {
+  return lbm_ibm_create_slab(out, x, y, n_markers, m_max, X, Y, 0);
+}
+
+int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
+                        int X, int Y, int row_offset) {
   LBM_REQUIRE(out && x && y && n_markers > 0, "lbm_ibm_create: bad argument");
   LBM_REQUIRE(m_max >= 2, "lbm_ibm_create: m_max=%d (need >= 2 for one forcing iteration)", m_max);
   // ROI, ibm.cpp:124-153
@@ -161,9 +166,11 @@ int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_marker
     c_min = std::min<long>(c_min, fy - 2);
     c_max = std::max<long>(c_max, fy + 2);
   }
-  LBM_REQUIRE(r_min >= 1 && c_min >= 1 && r_max + 1 <= X - 1 && c_max + 1 <= Y - 1,
-              "lbm_ibm_create: ROI rows [%ld,%ld] cols [%ld,%ld] must lie strictly inside the %dx%d lattice",
-              r_min, r_max, c_min, c_max, X, Y);
+  // X rows of this block / slab start at global row `row_offset`; weights are computed from the
+  // GLOBAL coordinates (as the reference does), only the stored ROI origin is slab-local
+  LBM_REQUIRE(r_min - row_offset >= 1 && c_min >= 1 && r_max + 1 - row_offset <= X - 1 && c_max + 1 <= Y - 1,
+              "lbm_ibm_create: ROI rows [%ld,%ld] cols [%ld,%ld] must lie strictly inside rows [%d,%d) x %d columns",
+              r_min, r_max, c_min, c_max, row_offset, row_offset + X, Y);
   const int RR = (int)(r_max - r_min + 1), RC = (int)(c_max - c_min + 1), n = RR * RC;
   std::vector<int> box0(n_markers);
   std::vector<double> phi((size_t)n_markers * 16);
@@ -198,7 +205,7 @@ int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_marker
   lbm_ibm* ib = new (std::nothrow) lbm_ibm();
   LBM_REQUIRE(ib, "lbm_ibm_create: out of host memory");
   ib->m_max = m_max;
-  ib->r1 = (int)r_max + 1;
+  ib->r1 = (int)r_max + 1 - row_offset;
   ib->c1 = (int)c_max + 1;
   ib->dev_blob = nullptr;
   ib->u_roi = ib->rho_roi = ib->F_sum = ib->fj = ib->out2 = nullptr;
@@ -228,7 +235,7 @@ int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_marker
   char* base = static_cast<char*>(ib->dev_blob);
   const double* dd = reinterpret_cast<const double*>(base);
   const int* di = reinterpret_cast<const int*>(base + n_dbl * 8);
-  ib->d = IbmDev{n_markers, RR, RC, (int)r_min, (int)c_min, X, Y, di, dd,
+  ib->d = IbmDev{n_markers, RR, RC, (int)r_min - row_offset, (int)c_min, X, Y, di, dd,
                  di + box0.size(), di + box0.size() + csr_ptr.size(), dd + phi.size()};
   *out = ib;
   return LBM_OK;
@@ -273,9 +280,11 @@ int lbm_ibm_force(lbm_ibm* ib, const double* u, const double* rho, double* F_out
 int lbm_ibm_add_source(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, double omega,
                        double a, double b, lbm_stream_t s) {
   LBM_REQUIRE(ib && p && g && u, "lbm_ibm_add_source: NULL argument");
-  LBM_REQUIRE(g->R == ib->d.X && g->C == ib->d.Y && g->ghost == 0,
-              "lbm_ibm_add_source: lattice %dx%d (ghost %d) does not match the boundary's %dx%d",
-              g->R, g->C, g->ghost, ib->d.X, ib->d.Y);
+  // a slab passes its own geometry (ghost rows allowed) and created the boundary in slab-local
+  // row coordinates; u is the slab's [2][R][C] moment field (no ghost rows)
+  LBM_REQUIRE(g->R == ib->d.X && g->C == ib->d.Y,
+              "lbm_ibm_add_source: lattice %dx%d does not match the boundary's %dx%d", g->R, g->C,
+              ib->d.X, ib->d.Y);
   const int n = ib->d.RR * ib->d.RC;
   LBM_KLAUNCH(k_ibm_add_source, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), ib->d, p,
               make_geom(*g), u, ib->F_sum, omega, a, b);

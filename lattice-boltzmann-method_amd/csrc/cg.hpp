@@ -120,13 +120,37 @@ __device__ __forceinline__ constexpr double cg_xi(int i, int j) {
   return XI[i][j];
 }
 
+// Macroscopic fields of a slab carry CG_MG = 2 ghost rows per side when the populations carry
+// ghost rows (lbm_geom.ghost = 3): pass A recomputes rho_r, rho_b, u on rows -2..R+1 from the
+// populations' 3 ghost rows, so one population exchange per step feeds both the streaming and
+// the 5x5 stencils.  Single block (ghost = 0): no macro ghost rows.
+struct MacroIdx {
+  int mg;   // macro ghost rows per side (0 or 2)
+  int C;
+  long n;   // doubles per macro plane = (R + 2*mg) * C
+  __host__ __device__ long at(int r, int c) const { return (long)(r + mg) * C + c; }
+};
+inline MacroIdx make_macro_idx(const Geom& g) {
+  const int mg = g.ghost ? 2 : 0;
+  return MacroIdx{mg, g.C, (long)(g.R + 2 * mg) * g.C};
+}
+// rows on which the macroscopic fields exist / the stencil may read: clamped at GLOBAL edges
+// only (replicate padding); a HALO edge continues into the neighbour's rows
+__host__ __device__ inline int cg_row_lo(const Geom& g, const Bc& bc) {
+  return (g.ghost && bc.row_lo == LBM_EDGE_HALO) ? -2 : 0;
+}
+__host__ __device__ inline int cg_row_hi(const Geom& g, const Bc& bc) {  // inclusive
+  return (g.ghost && bc.row_hi == LBM_EDGE_HALO) ? g.R + 1 : g.R - 1;
+}
+
 // ---- pass A ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cg_stream_moments(
     double* __restrict__ rho_r, double* __restrict__ rho_b, double* __restrict__ u,
-    const double* __restrict__ p_r, const double* __restrict__ p_b, Geom g, Bc bc, double grav) {
-  const long n = (long)g.R * g.C;
+    const double* __restrict__ p_r, const double* __restrict__ p_b, Geom g, Bc bc, double grav,
+    MacroIdx mi, int row_lo, int row_hi /* exclusive */) {
+  const long n = (long)(row_hi - row_lo) * g.C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int r = (int)(i / g.C), c = (int)(i % g.C);
+    const int r = row_lo + (int)(i / g.C), c = (int)(i % g.C);
     double fr[Q], fb[Q];
     gather_bc(fr, p_r, g, bc, r, c);
     gather_bc(fb, p_b, g, bc, r, c);
@@ -138,10 +162,11 @@ __global__ __launch_bounds__(256) void k_cg_stream_moments(
     double dummy;
     BgkModel::moments(ft, dummy, jx, jy);
     const double rt = rr + rb;  // :474
-    rho_r[i] = rr;
-    rho_b[i] = rb;
-    u[i] = jx / rt + 0.5 * grav / rt;      // :477, Fg = (g, 0)
-    u[n + i] = jy / rt + 0.5 * 0.0 / rt;
+    const long o = mi.at(r, c);
+    rho_r[o] = rr;
+    rho_b[o] = rb;
+    u[o] = jx / rt + 0.5 * grav / rt;      // :477, Fg = (g, 0)
+    u[mi.n + o] = jy / rt + 0.5 * 0.0 / rt;
   }
 }
 
@@ -157,19 +182,22 @@ __global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
     double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
     const double* __restrict__ in_b, const double* __restrict__ rho_r,
     const double* __restrict__ rho_b, const double* __restrict__ u, Geom g, Bc bc, CgConsts cc,
-    double* __restrict__ psi_out, double* __restrict__ snu_out) {
+    double* __restrict__ psi_out, double* __restrict__ snu_out, MacroIdx mi, int row_begin,
+    int row_end) {
   __shared__ double s_psi[CG_LR][CG_LC + 1];
   __shared__ double s_q[4][CG_LR][CG_LC + 1];  // Qx_r, Qy_r, Qx_b, Qy_b
   const int tiles_c = (g.C + CG_TC - 1) / CG_TC;
-  const int r_base = (blockIdx.x / tiles_c) * CG_TR, c_base = (blockIdx.x % tiles_c) * CG_TC;
-  const long n = (long)g.R * g.C;
-  // stage the stencil inputs; replicate padding = clamp (differential.cpp:5-9)
+  const int r_base = row_begin + (blockIdx.x / tiles_c) * CG_TR, c_base = (blockIdx.x % tiles_c) * CG_TC;
+  const long n = mi.n;
+  const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
+  // stage the stencil inputs; replicate padding = clamp (differential.cpp:5-9) at the edges of
+  // the GLOBAL domain, neighbour rows across a slab seam
   for (int i = threadIdx.x; i < CG_LR * CG_LC; i += 256) {
     const int lr = i / CG_LC, lc = i % CG_LC;
     int gr = r_base + lr - 2, gc = c_base + lc - 2;
-    gr = gr < 0 ? 0 : (gr > g.R - 1 ? g.R - 1 : gr);
+    gr = gr < rlo ? rlo : (gr > rhi ? rhi : gr);
     gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
-    const long o = (long)gr * g.C + gc;
+    const long o = mi.at(gr, gc);
     const double rr = rho_r[o], rb = rho_b[o], ux = u[o], uy = u[n + o];
     s_psi[lr][lc] = cg_psi(cc, rr, rb);
     s_q[0][lr][lc] = cc.k[0].qcoef * rr * ux;  // (1.8 alpha - 0.8) * rho_k * u_x  (:326)
@@ -180,7 +208,7 @@ __global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
   __syncthreads();
   const int tr = threadIdx.x / CG_TC, tc = threadIdx.x % CG_TC;
   const int r = r_base + tr, c = c_base + tc;
-  if (r >= g.R || c >= g.C) return;
+  if (r >= row_end || c >= g.C) return;
 
   // 5x5 cross-correlations, taps in (i, j) row-major order as conv2d lays them out
   double gx = 0.0, gy = 0.0, dxq[2] = {0.0, 0.0}, dyq[2] = {0.0, 0.0};
@@ -202,7 +230,7 @@ __global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
       }
     }
 
-  const long o = (long)r * g.C + c;
+  const long o = mi.at(r, c);
   const double rr = rho_r[o], rb = rho_b[o], ux = u[o], uy = u[n + o];
   const double rt = rr + rb;
   const double psi = s_psi[tr + 2][tc + 2];
@@ -272,8 +300,9 @@ __global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
     pn_b[q * g.plane + lo] = (rb * tot[q] / rt + cc.k[1].beta * kappa) + Fq;  // :464
   }
   if (WITH_FIELDS) {
-    psi_out[o] = psi;
-    snu_out[o] = s_nu;
+    const long oo = (long)r * g.C + c;  // diagnostics carry no ghost rows
+    psi_out[oo] = psi;
+    snu_out[oo] = s_nu;
   }
 }
 

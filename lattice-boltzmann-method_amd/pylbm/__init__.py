@@ -35,9 +35,13 @@ class Bc(ct.Structure):
                 ("col_hi", ct.c_int), ("pressure_rows", ct.c_int), ("rho_inlet", ct.c_double),
                 ("rho_outlet", ct.c_double), ("uw_r", ct.c_double), ("uw_c", ct.c_double)]
 
+    def __init__(self, row_lo=0, row_hi=0, col_lo=0, col_hi=0, pressure_rows=0, rho_inlet=1.0,
+                 rho_outlet=1.0, uw_r=0.0, uw_c=0.0):
+        super().__init__(row_lo, row_hi, col_lo, col_hi, pressure_rows, rho_inlet, rho_outlet, uw_r, uw_c)
+
     @staticmethod
     def periodic():
-        return Bc(0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0)
+        return Bc()
 
 
 class BgkParams(ct.Structure):
@@ -235,12 +239,13 @@ class CgSolver:
 class Ibm:
     """Python face of lbm_ibm (immersed boundary, stationary markers)."""
 
-    def __init__(self, lib, x, y, X, Y, m_max=5):
+    def __init__(self, lib, x, y, X, Y, m_max=5, row_offset=0):
         self.lib = lib
         x = np.ascontiguousarray(x, dtype=np.float64)
         y = np.ascontiguousarray(y, dtype=np.float64)
         self.h = ct.c_void_p()
-        lib.ibm_create(ct.byref(self.h), _hptr(x), _hptr(y), len(x), int(m_max), int(X), int(Y))
+        lib.ibm_create_slab(ct.byref(self.h), _hptr(x), _hptr(y), len(x), int(m_max), int(X), int(Y),
+                            int(row_offset))
 
     def roi(self):
         v = [ct.c_int() for _ in range(4)]

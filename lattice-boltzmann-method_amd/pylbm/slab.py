@@ -33,8 +33,37 @@ REST = (0, 2, 4)     # c_x = 0
 
 # (populations, owned row counted from the sending edge) per ghost depth; the receiver stores
 # them in the ghost row at the same distance from ITS edge.
-HALO_TO_NEXT = {1: [(TO_NEXT, 0)], 2: [(REST + TO_NEXT, 0), (TO_NEXT, 1)]}
-HALO_TO_PREV = {1: [(TO_PREV, 0)], 2: [(REST + TO_PREV, 0), (TO_PREV, 1)]}
+ALL9 = tuple(range(9))
+HALO_TO_NEXT = {1: [(TO_NEXT, 0)], 2: [(REST + TO_NEXT, 0), (TO_NEXT, 1)],
+                3: [(ALL9, 0), (REST + TO_NEXT, 1), (TO_NEXT, 2)]}
+HALO_TO_PREV = {1: [(TO_PREV, 0)], 2: [(REST + TO_PREV, 0), (TO_PREV, 1)],
+                3: [(ALL9, 0), (REST + TO_PREV, 1), (TO_PREV, 2)]}
+# depth 3 = the colour-gradient step: pass A recomputes the macroscopic fields on ghost rows
+# -2..-1 (R..R+1), whose own streaming reaches one row further out.
+
+
+def halo_ops(lats, G, R, next_rank, prev_rank):
+    """P2P ops that bring the ghost rows of every lattice in `lats` (views [9, R+2G, C]) up to
+    date.  Sends are issued (to next, to prev), receives (from prev, from next): with two ranks
+    both neighbours are the same peer and messages match in issue order."""
+    ops = []
+    for f, lat in enumerate(lats):
+        tag0 = 100 * f
+        if next_rank is not None:   # my last rows -> their ghost rows above row 0
+            for pops, k in HALO_TO_NEXT[G]:
+                ops += [dist.P2POp(dist.isend, lat[q, G + R - 1 - k], next_rank, tag=tag0 + 10 * k + q) for q in pops]
+        if prev_rank is not None:   # my first rows -> their ghost rows below row R-1
+            for pops, k in HALO_TO_PREV[G]:
+                ops += [dist.P2POp(dist.isend, lat[q, G + k], prev_rank, tag=tag0 + 10 * k + q) for q in pops]
+    for f, lat in enumerate(lats):
+        tag0 = 100 * f
+        if prev_rank is not None:
+            for pops, k in HALO_TO_NEXT[G]:
+                ops += [dist.P2POp(dist.irecv, lat[q, G - 1 - k], prev_rank, tag=tag0 + 10 * k + q) for q in pops]
+        if next_rank is not None:
+            for pops, k in HALO_TO_PREV[G]:
+                ops += [dist.P2POp(dist.irecv, lat[q, G + R + k], next_rank, tag=tag0 + 10 * k + q) for q in pops]
+    return ops
 
 
 class SlabRing:
@@ -83,25 +112,10 @@ class SlabRing:
         return self.owned().sum()
 
     def exchange(self, lat):
-        """Post the halo messages for `lat`; returns the outstanding requests.  Sends are
-        issued (to next, to prev), receives (from prev, from next): with two ranks both
-        neighbours are the same peer and messages match in issue order."""
-        G, R = self.ghost, self.R
-        if not G:
+        """Post the halo messages for `lat`; returns the outstanding requests."""
+        if not self.ghost:
             return []
-        ops = []
-        if self.next_rank is not None:   # my last rows -> their ghost rows above row 0
-            for pops, k in HALO_TO_NEXT[G]:
-                ops += [dist.P2POp(dist.isend, lat[q, G + R - 1 - k], self.next_rank, tag=10 * k + q) for q in pops]
-        if self.prev_rank is not None:   # my first rows -> their ghost rows below row R-1
-            for pops, k in HALO_TO_PREV[G]:
-                ops += [dist.P2POp(dist.isend, lat[q, G + k], self.prev_rank, tag=10 * k + q) for q in pops]
-        if self.prev_rank is not None:
-            for pops, k in HALO_TO_NEXT[G]:
-                ops += [dist.P2POp(dist.irecv, lat[q, G - 1 - k], self.prev_rank, tag=10 * k + q) for q in pops]
-        if self.next_rank is not None:
-            for pops, k in HALO_TO_PREV[G]:
-                ops += [dist.P2POp(dist.irecv, lat[q, G + R + k], self.next_rank, tag=10 * k + q) for q in pops]
+        ops = halo_ops([lat], self.ghost, self.R, self.next_rank, self.prev_rank)
         return dist.batch_isend_irecv(ops) if ops else []
 
     # -- state ---------------------------------------------------------------------------
@@ -185,3 +199,78 @@ class SlabRing:
         self.schedule = int(t[1] < t[0])
         self.autotune_ms = [float(x) / max(steps, 1) for x in t]
         return self.schedule
+
+
+class CgSlabRing:
+    """Colour-gradient (two-phase) step over a CHAIN of row slabs (the driver's rows 0 / R-1 are
+    bounce-back walls, test/mrtcg_rayleigh_taylor.cpp:525-531): two colour lattices with 3 ghost
+    rows, macroscopic fields with 2.  Per step: pass A on rows -2..R+1 (where a neighbour exists),
+    pass B on the 3 edge rows at each end, ONE exchange of 3 rows x both colours per side,
+    pass B on the interior rows meanwhile."""
+    G = 3
+
+    def __init__(self, lib, R, C, rank, world, dev, params, plane_pad=None):
+        from . import Bc
+        import ctypes
+        self.lib, self.R, self.C, self.rank, self.world, self.dev, self.params = lib, R, C, rank, world, dev, params
+        G = self.G if world > 1 else 0
+        self.ghost = G
+        rows = R + 2 * G
+        if plane_pad is None:
+            plane_pad = lib.default_plane_pad(rows, C) if lib is not None else 0
+        self.plane = rows * C + plane_pad
+        self.geom = Geom(R, C, G, self.plane if plane_pad else 0)
+        self.bc = Bc()
+        if lib is not None:
+            lib.raw.lbm_cg_default_bc(ctypes.byref(self.bc))
+        if G:
+            if rank > 0:
+                self.bc.row_lo = EDGE_HALO
+            if rank < world - 1:
+                self.bc.row_hi = EDGE_HALO
+        self.next_rank = rank + 1 if rank < world - 1 else None
+        self.prev_rank = rank - 1 if rank > 0 else None
+        z = lambda n: torch.zeros(n, dtype=torch.float64, device=dev)
+        self.buf = [[z(9 * self.plane) for _ in range(2)] for _ in range(2)]           # [buffer][colour]
+        self.lat = [[b.as_strided((9, rows, C), (self.plane, C, 1)) for b in bb] for bb in self.buf]
+        mg = 2 if G else 0
+        self.rho_r, self.rho_b, self.u = z((R + 2 * mg) * C), z((R + 2 * mg) * C), z(2 * (R + 2 * mg) * C)
+        self.cur = 0
+        self.side = None
+
+    def exchange(self, lats):
+        if not self.ghost:
+            return []
+        ops = halo_ops(lats, self.ghost, self.R, self.next_rank, self.prev_rank)
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def step(self, moments, collide_rows):
+        """moments(rho_r, rho_b, u, src_r, src_b, geom, bc); collide_rows(dst_r, dst_b, src_r, src_b,
+        rho_r, rho_b, u, geom, bc, r0, r1) -- both enqueue on the current torch stream."""
+        src, dst = self.lat[self.cur], self.lat[self.cur ^ 1]
+        R, e = self.R, self.G
+        moments(self.rho_r, self.rho_b, self.u, src[0], src[1], self.geom, self.bc)
+        args = (dst[0], dst[1], src[0], src[1], self.rho_r, self.rho_b, self.u, self.geom, self.bc)
+        if not self.ghost:
+            collide_rows(*args, 0, R)
+        elif self.dev.type != "cuda":
+            collide_rows(*args, 0, e)
+            collide_rows(*args, R - e, R)
+            reqs = self.exchange(dst)
+            collide_rows(*args, e, R - e)
+            for req in reqs:
+                req.wait()
+        else:
+            cur = torch.cuda.current_stream(self.dev)
+            if self.side is None:
+                self.side = torch.cuda.Stream(self.dev, priority=torch.cuda.Stream.priority_range()[1])
+            side = self.side
+            side.wait_stream(cur)           # pass A done, previous step done
+            with torch.cuda.stream(side):   # interior on the side stream (see SlabRing.step)
+                collide_rows(*args, e, R - e)
+            collide_rows(*args, 0, e)
+            collide_rows(*args, R - e, R)
+            for req in self.exchange(dst):
+                req.wait()
+            cur.wait_stream(side)
+        self.cur ^= 1

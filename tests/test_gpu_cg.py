@@ -68,3 +68,80 @@ def test_cg_large_box_vs_oracle(lib, oracle):
         for k in ("rho_r", "rho_b"):
             assert abs(got[k].sum() - s0[k].sum()) / s0[k].sum() < 1e-9
         assert (got["psi"][: R // 4] > 0.99).all() and (got["psi"][-R // 4:] < -0.99).all()
+
+
+def test_cg_two_slabs_equal_single_block(lib, oracle):
+    """Config 4 over slabs: 2 slabs emulated on one GPU.  Populations carry 3 ghost rows, filled
+    by hand with the rows a neighbour would send; the macroscopic fields are recomputed on 2 ghost
+    rows by pass A; bounce-back rows stay on the outer slabs, the seam is HALO.  Result must equal
+    the single block (and hence the oracle) bitwise."""
+    import ctypes as ct
+    from gpu_util import dev, download_aos, upload_soa
+    from pylbm import _ptr
+    Rg, C, n, G = 64, 64, 12, 3
+    R = Rg // 2
+    po = pyoracle.cg_params(Rg, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    want = oracle.cg_steps(po, s0, n)
+    d = dev()
+    flat = pylbm.Geom(Rg, C, 0)
+    bc_flat = pylbm.Bc()
+    lib.raw.lbm_cg_default_bc(ct.byref(bc_flat))
+    # first iteration on the whole block (given rho, u), then split the post-collision lattices
+    f_r, f_b = upload_soa(lib, s0["f_r"]), upload_soa(lib, s0["f_b"])
+    rr, rb, uu = upload_soa(lib, s0["rho_r"]), upload_soa(lib, s0["rho_b"]), upload_soa(lib, s0["u"])
+    p_r = torch.empty((9, Rg, C), dtype=torch.float64, device=d)
+    p_b = torch.empty_like(p_r)
+    lib.cg_collide(_ptr(p_r), _ptr(p_b), _ptr(f_r), _ptr(f_b), _ptr(rr), _ptr(rb), _ptr(uu),
+                   ct.byref(flat), ct.byref(bc_flat), ct.byref(pg), None, None, None)
+    torch.cuda.synchronize()
+    geom = pylbm.Geom(R, C, G)
+    bcs = []
+    for s in range(2):
+        b = pylbm.Bc()
+        lib.raw.lbm_cg_default_bc(ct.byref(b))
+        if s == 0:
+            b.row_hi = pylbm.EDGE_HALO
+        else:
+            b.row_lo = pylbm.EDGE_HALO
+        bcs.append(b)
+    lat = [[[torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=d) for _ in range(2)]
+            for _ in range(2)] for _ in range(2)]          # [slab][buffer][colour]
+    mac = [[torch.zeros(((R + 4), C), dtype=torch.float64, device=d),
+            torch.zeros(((R + 4), C), dtype=torch.float64, device=d),
+            torch.zeros((2, (R + 4), C), dtype=torch.float64, device=d)] for _ in range(2)]
+
+    def halo(cur):   # chain of two: slab 0's last 3 rows <-> slab 1's first 3 rows, all populations
+        for k in range(2):
+            lat[1][cur][k][:, 0:G] = lat[0][cur][k][:, R:R + G]          # rows R-3..R-1 of slab 0
+            lat[0][cur][k][:, G + R:G + R + G] = lat[1][cur][k][:, G:2 * G]  # rows 0..2 of slab 1
+
+    for s in range(2):
+        lat[s][0][0][:, G:G + R] = p_r[:, s * R:(s + 1) * R]
+        lat[s][0][1][:, G:G + R] = p_b[:, s * R:(s + 1) * R]
+    halo(0)
+    cur = 0
+    for _ in range(n - 1):
+        for s in range(2):
+            src, dst, m = lat[s][cur], lat[s][cur ^ 1], mac[s]
+            lib.cg_stream_moments(_ptr(m[0]), _ptr(m[1]), _ptr(m[2]), _ptr(src[0]), _ptr(src[1]),
+                                  ct.byref(geom), ct.byref(bcs[s]), ct.byref(pg), None)
+            for r0, r1 in ((0, G), (R - G, R), (G, R - G)):   # edge rows first, as the overlap schedule does
+                lib.cg_stream_collide(_ptr(dst[0]), _ptr(dst[1]), _ptr(src[0]), _ptr(src[1]),
+                                      _ptr(m[0]), _ptr(m[1]), _ptr(m[2]), ct.byref(geom),
+                                      ct.byref(bcs[s]), ct.byref(pg), r0, r1, None, None, None)
+        torch.cuda.synchronize()
+        cur ^= 1
+        halo(cur)
+    # f_adve = stream(P) on the re-assembled block, moments through the single-block pass A
+    P = [torch.cat([lat[0][cur][k][:, G:G + R], lat[1][cur][k][:, G:G + R]], dim=1).contiguous() for k in range(2)]
+    out = torch.empty_like(P[0])
+    for k, key in ((0, "f_r"), (1, "f_b")):
+        lib.stream(_ptr(out), _ptr(P[k]), ct.byref(flat), ct.byref(bc_flat), None)
+        got = download_aos(lib, out)
+        assert bits_equal(got, want[key]), (key, ulp_diff(got, want[key]))
+    lib.cg_stream_moments(_ptr(rr), _ptr(rb), _ptr(uu), _ptr(P[0]), _ptr(P[1]), ct.byref(flat),
+                          ct.byref(bc_flat), ct.byref(pg), None)
+    assert bits_equal(download_aos(lib, rr), want["rho_r"])
+    assert bits_equal(download_aos(lib, uu), want["u"])

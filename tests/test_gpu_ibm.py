@@ -104,3 +104,76 @@ def test_cylinder_config5_scale_vs_oracle(lib, oracle):
     assert np.allclose(ib.surface_force(), Fso, rtol=1e-10)
     assert Fso[0] < 0  # the cylinder is dragged downstream: the fluid feels -drag
     sv.close(); ib.close()
+
+
+@pytest.mark.parametrize("owner", [0, 1])
+def test_cylinder_two_slabs_equal_single_block(lib, oracle, owner):
+    """Config 5 over slabs, emulated on one GPU: a chain of 2 slabs (anti-bounce-back inlet on
+    slab 0, outlet on slab 1, HALO seam, specular side walls); the immersed boundary is created in
+    slab-local coordinates on the slab that owns its ROI.  Equals the oracle's single block bitwise."""
+    from pylbm.slab import TO_NEXT, TO_PREV
+    X, Y, n = 128, 96, 9
+    R = X // 2
+    omega, u_in = 1.0 / 0.55, 0.05
+    x, y = circle(32.37 + owner * R, 48.21, 10.0)
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+    fo, uo, rhoo, Fso = oracle.cylinder_steps(x, y, f0, omega, u_in, n)
+    d = dev()
+    prm = pylbm.BgkParams(omega, 0, 1)
+    a, b = 1.0 / 3.0, 1.0 / 9.0
+
+    def mkbc(lo, hi):
+        bc = pylbm.Bc(row_lo=lo, row_hi=hi, col_lo=pylbm.EDGE_SPECULAR, col_hi=pylbm.EDGE_SPECULAR)
+        bc.uw_r = u_in
+        return bc
+    ABB, HALO = pylbm.EDGE_ABB_VELOCITY, pylbm.EDGE_HALO
+    flat, bc_flat = pylbm.Geom(X, Y, 0), mkbc(ABB, ABB)
+    # first iteration on the whole block: collide, IBM force, Guo source on the ROI
+    ib_flat = pylbm.Ibm(lib, x, y, X, Y)
+    f0d = upload_soa(lib, f0)
+    p0 = torch.empty((9, X, Y), dtype=torch.float64, device=d)
+    rho = torch.empty((X, Y), dtype=torch.float64, device=d)
+    u = torch.empty((2, X, Y), dtype=torch.float64, device=d)
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(flat), ct.byref(bc_flat), ct.byref(prm), _ptr(rho), _ptr(u), None)
+    lib.ibm_force(ib_flat.h, _ptr(u), _ptr(rho), None, None)
+    lib.ibm_add_source(ib_flat.h, _ptr(p0), ct.byref(flat), _ptr(u), ct.c_double(omega), ct.c_double(a), ct.c_double(b), None)
+    torch.cuda.synchronize()
+    # slabs: ghost = 1; the cylinder (rows ~20..45) belongs to slab 0
+    geom = pylbm.Geom(R, Y, 1)
+    bcs = [mkbc(ABB, HALO), mkbc(HALO, ABB)]
+    ib0 = pylbm.Ibm(lib, x, y, R, Y, row_offset=owner * R)   # global marker coordinates, slab-local ROI
+    assert 1 <= ib0.roi()[0] and ib0.roi()[1] <= R - 1
+    lat = [[torch.zeros((9, R + 2, Y), dtype=torch.float64, device=d) for _ in range(2)] for _ in range(2)]
+    mom = [(torch.empty((R, Y), dtype=torch.float64, device=d), torch.empty((2, R, Y), dtype=torch.float64, device=d)) for _ in range(2)]
+
+    def halo(cur):
+        for q in TO_NEXT:
+            lat[1][cur][q, 0] = lat[0][cur][q, R]
+        for q in TO_PREV:
+            lat[0][cur][q, R + 1] = lat[1][cur][q, 1]
+    for s in range(2):
+        lat[s][0][:, 1:R + 1] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    cur = 0
+    for _ in range(n - 1):
+        for s in range(2):
+            src, dst = lat[s][cur], lat[s][cur ^ 1]
+            rs, us = mom[s]
+            for r0, r1 in ((0, 1), (R - 1, R), (1, R - 1)):
+                lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bcs[s]), ct.byref(prm),
+                                       r0, r1, _ptr(rs), _ptr(us), None)
+            if s == owner:
+                lib.ibm_force(ib0.h, _ptr(us), _ptr(rs), None, None)
+                lib.ibm_add_source(ib0.h, _ptr(dst), ct.byref(geom), _ptr(us), ct.c_double(omega),
+                                   ct.c_double(a), ct.c_double(b), None)
+        torch.cuda.synchronize()
+        cur ^= 1
+        halo(cur)
+    P = torch.cat([lat[0][cur][:, 1:R + 1], lat[1][cur][:, 1:R + 1]], dim=1).contiguous()
+    out = torch.empty_like(P)
+    lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc_flat), None)
+    got = download_aos(lib, out)
+    assert bits_equal(got, fo), ulp_diff(got, fo)
+    assert np.allclose(ib0.surface_force(), Fso, rtol=1e-11, atol=1e-16)
+    ib0.close(); ib_flat.close()

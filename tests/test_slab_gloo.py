@@ -129,3 +129,45 @@ def test_ring_neighbours_and_edge_modes():
         assert ring.bc.row_lo == (EDGE_BOUNCE_BACK if rank == 0 else EDGE_HALO)
         assert ring.bc.row_hi == (EDGE_BOUNCE_BACK if rank == 3 else EDGE_HALO)
         assert ring.lat[0].shape == (9, 6, 8) and ring.geom.ghost == 1
+
+
+def exchange_worker(rank, world, port, R, C, out_dir):
+    """depth-3 chain exchange of two lattices (the colour-gradient ring), no compute: every
+    entry encodes (rank, field, q, row) so the ghost rows can be checked exactly."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pylbm.slab import CgSlabRing
+    ring = CgSlabRing(None, R, C, rank, world, torch.device("cpu"), None, plane_pad=5)
+    G = ring.ghost
+    for f in range(2):
+        lat = ring.lat[0][f]
+        lat.fill_(-1.0)
+        for q in range(9):
+            for r in range(R):
+                lat[q, G + r, :] = 1000 * rank + 100 * f + 10 * q + r
+    for req in ring.exchange(ring.lat[0]):
+        req.wait()
+    np.save(os.path.join(out_dir, f"lat{rank}.npy"), torch.stack(ring.lat[0]).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_colour_gradient_ring_exchange_depth3(tmp_path):
+    from pylbm.slab import HALO_TO_NEXT, HALO_TO_PREV
+    world, R, C, G = 3, 7, 4, 3
+    port = 29500 + (os.getpid() % 2000) + 77
+    mp.start_processes(exchange_worker, args=(world, port, R, C, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    lats = [np.load(tmp_path / f"lat{r}.npy") for r in range(world)]   # [field, 9, R+6, C]
+    val = lambda rank, f, q, r: 1000 * rank + 100 * f + 10 * q + r
+    for rank in range(world):
+        for f in range(2):
+            a = lats[rank][f]
+            for q in range(9):
+                for k in range(3):
+                    above, below = a[q, G - 1 - k, 0], a[q, G + R + k, 0]
+                    need_above = any(q in pops and kk == k for pops, kk in HALO_TO_NEXT[3])
+                    need_below = any(q in pops and kk == k for pops, kk in HALO_TO_PREV[3])
+                    # chain: no neighbour beyond the first / last slab -> ghost rows untouched
+                    assert above == (val(rank - 1, f, q, R - 1 - k) if rank > 0 and need_above else -1.0)
+                    assert below == (val(rank + 1, f, q, k) if rank < world - 1 and need_below else -1.0)
