@@ -33,7 +33,7 @@ def test_argument_validation_needs_no_gpu():
         lib.bgk_stream_collide(None, None, ct.byref(g), None, ct.byref(bad), 0, 16, None, None, None)
     bc = pylbm.Bc.periodic()
     bc.row_lo = pylbm.EDGE_HALO
-    with pytest.raises(pylbm.LbmError, match="HALO rows need ghost=1"):
+    with pytest.raises(pylbm.LbmError, match="HALO rows need ghost rows"):
         lib.bgk_stream_collide(None, None, ct.byref(g), ct.byref(bc), ct.byref(prm), 0, 16, None, None, None)
     with pytest.raises(pylbm.LbmError, match="NULL"):
         lib.calc_rho(None, None, 4, 4, None)
