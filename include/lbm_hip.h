@@ -123,6 +123,13 @@ typedef struct lbm_bgk_params {
   int delta_form;     /* how the driver writes the relaxation (different rounding, same maths):
                          0: f* = (1-omega) f + omega feq        solver::collision, solver.cpp:73
                          1: f* = f + (-omega (f - feq))          cylinder_test.cpp:108,123-125 */
+  /* constant body force as test/gravity_test.cpp applies it: force_mode = 1:
+     u += (force_r, force_c) before the equilibrium (:146), and the source
+     S_q = (1 - omega/2) w_q [(guo_a + guo_b c_q.u)(c_q.F) - guo_a u.F] (:154, (1/3, 1/9) there) is
+     added to the post-collision populations: f* = f + (-omega (f - feq)) + S (:158-160);
+     implies delta_form.  force_mode = 0: off. */
+  int force_mode;
+  double force_r, force_c, guo_a, guo_b;
 } lbm_bgk_params;
 
 /* P = collide(f): moments, equilibrium, collision of every node in place of one driver

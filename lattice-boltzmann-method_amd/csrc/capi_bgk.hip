@@ -59,6 +59,7 @@ static int launch_pressure_rows(bool from_post, double* pn, const double* in, co
 static int check_bgk(const char* fn, const lbm_bgk_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->omega > 0.0 && prm->omega < 2.0, "%s: omega=%g outside (0, 2)", fn, prm->omega);
+  LBM_REQUIRE(prm->force_mode == 0 || prm->force_mode == 1, "%s: force_mode=%d", fn, prm->force_mode);
   return LBM_OK;
 }
 
@@ -72,7 +73,7 @@ int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
                     const lbm_bgk_params* prm, double* rho, double* u, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_collide", prm);
   if (rc) return rc;
-  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form};
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   rc = launch_collide_only("lbm_bgk_collide", p, f, g, bc, m, rho, u, as_stream(s));
   if (rc) return rc;
   if (bc && bc->pressure_rows) {
@@ -88,7 +89,7 @@ int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            int row_end, double* rho, double* u, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_stream_collide", prm);
   if (rc) return rc;
-  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form};
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   rc = launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, m, row_begin, row_end,
                              rho, u, as_stream(s));
   if (rc) return rc;
@@ -105,7 +106,7 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
                               int row_end, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_stream_collide_x2", prm);
   if (rc) return rc;
-  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form};
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, m, row_begin,
                                   row_end, as_stream(s));
 }

@@ -139,6 +139,8 @@ struct BgkModel {
   double omega;
   int incompressible;
   int delta_form;  // see lbm_bgk_params
+  int force_mode;  // 1: gravity_test.cpp body force
+  double Fr, Fc, ga, gb;
 
   __device__ __forceinline__ static void moments(const double (&f)[Q], double& rho, double& jx,
                                                  double& jy) {
@@ -177,8 +179,21 @@ struct BgkModel {
       ux = jx / rho;
       uy = jy / rho;
     }
+    if (force_mode) {  // gravity_test.cpp:146  u += Fg.t()
+      ux += Fr;
+      uy += Fc;
+    }
     feq(e, rho, ux, uy);
-    if (delta_form) {
+    if (force_mode) {  // gravity_test.cpp:151-160: f + (-omega (f - feq)) + S
+      const double uF = ux * Fr + uy * Fc;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+        const double cF = Fr * (double)icx(q) + Fc * (double)icy(q);
+        const double S = ((1 - 0.5 * omega) * ((ga + gb * cu) * cF - ga * uF) * wq(q));
+        f[q] = f[q] + (-omega * (f[q] - e[q])) + S;
+      }
+    } else if (delta_form) {
 #pragma unroll
       for (int q = 0; q < Q; ++q) f[q] = f[q] + (-omega * (f[q] - e[q]));  // cylinder_test.cpp:108,123
     } else {

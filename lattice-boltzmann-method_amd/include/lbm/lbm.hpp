@@ -107,7 +107,11 @@ class Solver {  // single-phase BGK / KBC block, wraps lbm_solver
  public:
   static Solver bgk(int R, int C, double omega, bool incompressible, const lbm_bc& bc = BoundarySet(),
                     bool delta_form = false) {
-    lbm_bgk_params p{omega, incompressible ? 1 : 0, delta_form ? 1 : 0};
+    lbm_bgk_params p{omega, incompressible ? 1 : 0, delta_form ? 1 : 0, 0, 0.0, 0.0, 0.0, 0.0};
+    return Solver(LBM_MODEL_BGK, R, C, &p, bc);
+  }
+  // full parameter block (e.g. the body force of test/gravity_test.cpp: force_mode = 1)
+  static Solver bgk(int R, int C, const lbm_bgk_params& p, const lbm_bc& bc) {
     return Solver(LBM_MODEL_BGK, R, C, &p, bc);
   }
   static Solver kbc(int R, int C, double s2, const lbm_bc& bc = BoundarySet()) {

@@ -45,10 +45,16 @@ class Bc(ct.Structure):
 
 
 class BgkParams(ct.Structure):
-    _fields_ = [("omega", ct.c_double), ("incompressible", ct.c_int), ("delta_form", ct.c_int)]
+    _fields_ = [("omega", ct.c_double), ("incompressible", ct.c_int), ("delta_form", ct.c_int),
+                ("force_mode", ct.c_int), ("force_r", ct.c_double), ("force_c", ct.c_double),
+                ("guo_a", ct.c_double), ("guo_b", ct.c_double)]
 
-    def __init__(self, omega=1.0, incompressible=0, delta_form=0):
-        super().__init__(omega, incompressible, delta_form)
+    def __init__(self, omega=1.0, incompressible=0, delta_form=0, force=None, guo=(1.0 / 3.0, 1.0 / 9.0)):
+        """force=(Fr, Fc): the body force of test/gravity_test.cpp (u += F, Guo-type source)"""
+        if force is None:
+            super().__init__(omega, incompressible, delta_form, 0, 0.0, 0.0, 0.0, 0.0)
+        else:
+            super().__init__(omega, incompressible, 1, 1, force[0], force[1], guo[0], guo[1])
 
 
 class KbcParams(ct.Structure):

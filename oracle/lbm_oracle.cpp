@@ -259,6 +259,125 @@ int orc_hpt_run(const orc_hpt_params* p, double* f_adve, double* u, double* rho,
 }
 
 // ---------------------------------------------------------------------------------
+// specular_boundary_test, free_stream_test, gravity_test
+// ---------------------------------------------------------------------------------
+static void specular_columns(double* f_adve, const double* f_coll, int H, int W) {
+  // specular_boundary_test.cpp:121-127 == cylinder_test.cpp:157-163
+  for (int r = 0; r < H; ++r) {
+    const size_t e = nid(r, W - 1, W) * 9, w = nid(r, 0, W) * 9;
+    f_adve[e + 4] = f_coll[e + 2];
+    f_adve[e + 7] = f_coll[e + 6];
+    f_adve[e + 8] = f_coll[e + 5];
+    f_adve[w + 2] = f_coll[w + 4];
+    f_adve[w + 5] = f_coll[w + 8];
+    f_adve[w + 6] = f_coll[w + 7];
+  }
+}
+
+void orc_sbt_run(int H, int W, int T, double omega, double rho_inlet, double rho_outlet,
+                 double* f_adve, double* u, double* rho) {
+  const size_t N = (size_t)H * W;
+  small_grid_guard sg(N);
+  std::vector<double> f_equi(N * 9), f_coll(N * 9);
+  for (size_t i = 0; i < N; ++i) {
+    rho[i] = 1.0;
+    u[2 * i] = u[2 * i + 1] = 0.0;
+  }
+  orc_incomp_equilibrium(f_adve, u, rho, H, W);  // :87 (incompressible init, compressible loop)
+  for (int t = 0; t < T; ++t) {
+    orc_calc_rho(rho, f_adve, H, W);             // :104
+    orc_calc_u(u, f_adve, rho, H, W);            // :105
+    orc_equilibrium(f_equi.data(), u, rho, H, W);                       // :108
+    orc_collision(f_coll.data(), f_adve, f_equi.data(), omega, H, W);   // :111
+    for (int e = 0; e < 2; ++e) {                // periodic_boundary_condition :23-45 (compressible feq)
+      const int dst = e ? H - 1 : 0, src = e ? 1 : H - 2;
+      for (int c = 0; c < W; ++c) {
+        double te[9];
+        const size_t s = nid(src, c, W);
+        node_feq(te, (e ? rho_outlet : rho_inlet) * 1.0, u[2 * s], u[2 * s + 1]);
+        for (int q = 0; q < 9; ++q)
+          f_coll[nid(dst, c, W) * 9 + q] = (te[q] + f_coll[s * 9 + q]) - f_equi[s * 9 + q];
+      }
+    }
+    advect(f_adve, f_coll.data(), H, W);                 // :117
+    specular_columns(f_adve, f_coll.data(), H, W);       // :120-127
+  }
+}
+
+void orc_free_stream_steps(double* f_adve, double* u, double* rho, int X, int Y, double omega,
+                           double uw, int nsteps) {
+  const size_t N = (size_t)X * Y;
+  small_grid_guard sg(N);
+  std::vector<double> f_equi(N * 9), f_coll(N * 9);
+  static const int OPP[9] = {0, 3, 4, 1, 2, 7, 8, 5, 6};
+  double abb[9];  // free_stream_test.cpp:104, :115 with u_w = (uw, 0)
+  for (int q = 0; q < 9; ++q) {
+    const double cu = uw * CX[q] + 0.0 * CY[q];
+    abb[q] = (2.0 + 9.0 * std::pow(cu, 2.0) - 3.0 * (uw * uw + 0.0 * 0.0)) * W9[q];
+  }
+  for (int t = 0; t < nsteps; ++t) {
+    orc_calc_rho(rho, f_adve, X, Y);                                    // :90
+    orc_calc_incomp_u(u, f_adve, X, Y);                                 // :91
+    orc_incomp_equilibrium(f_equi.data(), u, rho, X, Y);                // :94
+    orc_collision(f_coll.data(), f_adve, f_equi.data(), omega, X, Y);   // :97
+    advect(f_adve, f_coll.data(), X, Y);                                // :100
+    for (int e = 0; e < 2; ++e) {                                       // :102-124
+      const int r = e ? X - 1 : 0;
+      for (int c = 0; c < Y; ++c) {
+        const size_t n = nid(r, c, Y) * 9;
+        for (int q = 1; q < 9; ++q) f_adve[n + OPP[q]] = -f_coll[n + q] + abb[q];
+      }
+    }
+    specular_columns(f_adve, f_coll.data(), X, Y);                      // :126-133
+  }
+}
+
+int orc_gravity_run(int H, int W, int T, double omega, double Fr, double Fc, double rho_inlet,
+                    double rho_outlet, int check_convergence, double* f_adve, double* u, double* rho) {
+  const size_t N = (size_t)H * W;
+  small_grid_guard sg(N);
+  std::vector<double> f_equi(N * 9), f_coll(N * 9);
+  const double ics2 = 1.0 / 3.0, ics4 = 1.0 / 9.0;  // gravity_test.cpp:81-82
+  for (size_t i = 0; i < N; ++i) {
+    rho[i] = 1.0;
+    u[2 * i] = u[2 * i + 1] = 0.0;
+  }
+  orc_incomp_equilibrium(f_adve, u, rho, H, W);  // :103
+  double old_mean = 1.0;
+  int t = 0;
+  for (; t < T; ++t) {
+    if (check_convergence && t % 100 == 1) {  // :126-139
+      double m = 0.0;
+      for (size_t i = 0; i < N; ++i) m += u[2 * i];
+      m /= (double)N;
+      if (std::fabs(m / old_mean - 1.0) < 1e-12) break;
+      old_mean = m;
+    }
+    orc_calc_rho(rho, f_adve, H, W);         // :143
+    orc_calc_incomp_u(u, f_adve, H, W);      // :144
+    for (size_t i = 0; i < N; ++i) {         // u += Fg.t()  :146
+      u[2 * i] += Fr;
+      u[2 * i + 1] += Fc;
+    }
+    orc_incomp_equilibrium(f_equi.data(), u, rho, H, W);  // :150
+    for (size_t i = 0; i < N; ++i) {
+      const double ux = u[2 * i], uy = u[2 * i + 1];
+      const double uF = ux * Fr + uy * Fc;
+      for (int q = 0; q < 9; ++q) {
+        const double eqp = -omega * (f_adve[i * 9 + q] - f_equi[i * 9 + q]);  // :151
+        const double cu = ux * CX[q] + uy * CY[q], cF = Fr * CX[q] + Fc * CY[q];
+        const double S = ((1 - 0.5 * omega) * ((ics2 + ics4 * cu) * cF - ics2 * uF) * W9[q]);  // :154
+        f_coll[i * 9 + q] = f_adve[i * 9 + q] + eqp + S;  // :158-160
+      }
+    }
+    hpt_pressure_rows(f_coll.data(), f_equi.data(), u, H, W, rho_inlet, rho_outlet);  // :164 (incompressible)
+    advect(f_adve, f_coll.data(), H, W);                   // :168
+    bounce_back_columns(f_adve, f_coll.data(), H, W);      // :171-177
+  }
+  return t;
+}
+
+// ---------------------------------------------------------------------------------
 // test/decompose_domain.cpp
 // ---------------------------------------------------------------------------------
 void orc_ddm_run(int H, int W, int T, double omega, double rho_inlet, double rho_outlet,

@@ -38,6 +38,22 @@ typedef struct {
 /* returns the number of steps executed; f/u/rho = state when the loop ended. */
 int orc_hpt_run(const orc_hpt_params* p, double* f, double* u, double* rho, double* l2_out);
 
+/* ---- the remaining single-phase BGK drivers -------------------------------- */
+/* test/specular_boundary_test.cpp:47-139: compressible BGK, pressure-periodic rows with the
+ * compressible equilibrium (:23-45), specular columns (:121-127).  f/u/rho = state after T steps. */
+void orc_sbt_run(int H, int W, int T, double omega, double rho_inlet, double rho_outlet,
+                 double* f, double* u, double* rho);
+/* test/free_stream_test.cpp:75-131 loop body, nsteps times: incompressible BGK, anti-bounce-back
+ * rows with u_w = (uw, 0), specular columns.  f in/out. */
+void orc_free_stream_steps(double* f, double* u, double* rho, int X, int Y, double omega,
+                           double uw, int nsteps);
+/* test/gravity_test.cpp:62-181: incompressible BGK with body force Fg = (Fr, Fc): u += Fg (:142),
+ * relaxation in delta form plus the Guo-type source S with 1/3, 1/9 (:146-158), pressure-periodic
+ * rows (rho_in = rho_out), halfway bounce-back columns, the reference's convergence rule.
+ * Returns the number of steps executed. */
+int orc_gravity_run(int H, int W, int T, double omega, double Fr, double Fc, double rho_inlet,
+                    double rho_outlet, int check_convergence, double* f, double* u, double* rho);
+
 /* ---- test/decompose_domain.cpp:75-188: two blocks A (upstream) and B ---- */
 void orc_ddm_run(int H, int W, int T, double omega, double rho_inlet, double rho_outlet,
                  double* fA, double* fB, double* uA, double* uB, double* rhoA, double* rhoB);

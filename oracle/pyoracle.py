@@ -88,6 +88,7 @@ class Oracle:
         self.lib = ct.CDLL(path)
         self.lib.orc_max_threads.restype = ct.c_int
         self.lib.orc_hpt_run.restype = ct.c_int
+        self.lib.orc_gravity_run.restype = ct.c_int
 
     def max_threads(self):
         return self.lib.orc_max_threads()
@@ -140,6 +141,26 @@ class Oracle:
         l2 = ct.c_double(0.0)
         steps = self.lib.orc_hpt_run(ct.byref(p), _p(f), _p(u), _p(rho), ct.byref(l2))
         return dict(steps=steps, f=f, u=u, rho=rho, l2=l2.value)
+
+    def sbt_run(self, H, W, T, omega, rho_inlet, rho_outlet):
+        f = np.empty((H, W, 9)); u = np.empty((H, W, 2)); rho = np.empty((H, W))
+        self.lib.orc_sbt_run(H, W, int(T), ct.c_double(omega), ct.c_double(rho_inlet),
+                             ct.c_double(rho_outlet), _p(f), _p(u), _p(rho))
+        return dict(f=f, u=u, rho=rho)
+
+    def free_stream_steps(self, f, omega, uw, nsteps):
+        f = _c(f).copy(); X, Y, _ = f.shape
+        u = np.zeros((X, Y, 2)); rho = np.ones((X, Y))
+        self.lib.orc_free_stream_steps(_p(f), _p(u), _p(rho), X, Y, ct.c_double(omega),
+                                       ct.c_double(uw), int(nsteps))
+        return f, u, rho
+
+    def gravity_run(self, H, W, T, omega, Fr, Fc, rho_inlet=1.0, rho_outlet=1.0, check_convergence=True):
+        f = np.empty((H, W, 9)); u = np.empty((H, W, 2)); rho = np.empty((H, W))
+        steps = self.lib.orc_gravity_run(H, W, int(T), ct.c_double(omega), ct.c_double(Fr),
+                                         ct.c_double(Fc), ct.c_double(rho_inlet),
+                                         ct.c_double(rho_outlet), int(check_convergence), _p(f), _p(u), _p(rho))
+        return dict(steps=steps, f=f, u=u, rho=rho)
 
     def ddm_run(self, H, W, T, omega, rho_inlet, rho_outlet):
         out = {k: np.empty(s) for k, s in dict(fA=(H, W, 9), fB=(H, W, 9), uA=(H, W, 2),

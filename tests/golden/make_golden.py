@@ -84,6 +84,31 @@ def gen_hpt():
          uy=np.ascontiguousarray(uy[..., steps]), rho=np.ascontiguousarray(rho[..., steps]))
 
 
+def _run_main(exe, prefix, steps_fn, out_name, rho_from_ps=True):
+    """run an unmodified reference main that saves <prefix>-{fs,ux,uy,ps}.pt stacks over all T
+    steps and keep a few time slices (snapshot t = f_adve entering step t, moments of step t-1)"""
+    with tempfile.TemporaryDirectory() as d:
+        log = subprocess.run([os.path.join(REF_DIR, exe)], cwd=d, capture_output=True, text=True,
+                             check=True).stdout
+        ux, uy = load_pt(f"{d}/{prefix}-ux.pt"), load_pt(f"{d}/{prefix}-uy.pt")
+        rho = load_pt(f"{d}/{prefix}-ps.pt") * 3.0
+        fs = load_pt(f"{d}/{prefix}-fs.pt")
+    m = re.search(r"last t=(\d+)", log)
+    T = ux.shape[-1]
+    steps = steps_fn(T, int(m.group(1)) if m else None)
+    save(out_name, steps=steps, T=np.int64(T), last_t=np.int64(int(m.group(1)) if m else -1),
+         fs=np.ascontiguousarray(fs[..., steps]), ux=np.ascontiguousarray(ux[..., steps]),
+         uy=np.ascontiguousarray(uy[..., steps]), rho=np.ascontiguousarray(rho[..., steps]))
+
+
+def gen_sbt():  # test/specular_boundary_test.cpp, 51 x 51, T = 10000 (1.9 GB of snapshots in RAM)
+    _run_main("sbt", "sbt", lambda T, last: np.array([1, 2, 10, 100, 1000, T - 1]), "sbt_51x51.npz")
+
+
+def gen_gt():   # test/gravity_test.cpp, 21 x 21; stops by its own convergence rule ("last t=")
+    _run_main("gt", "gt", lambda T, last: np.array([1, 2, 10, 100, 1000, last]), "gt_21x21.npz")
+
+
 def gen_ddm():
     with tempfile.TemporaryDirectory() as d:
         subprocess.run([os.path.join(REF_DIR, "ddm")], cwd=d, capture_output=True, check=True)
@@ -145,5 +170,7 @@ if __name__ == "__main__":
     gen_diff(r)
     gen_hpt()
     gen_ddm()
+    gen_gt()
+    gen_sbt()
     if not a.skip_dsf:
         gen_dsf()

@@ -82,3 +82,38 @@ def test_cylinder_driver_vs_oracle(tmp_path, oracle):
     f = np.fromfile(tmp_path / "c-f.f64").reshape(X, Y, 9)
     assert relerr(f, fo) < 1e-12
     assert np.allclose([float(out["Fs_r"]), float(out["Fs_c"])], Fso, rtol=1e-10, atol=1e-16)
+
+
+def test_specular_boundary_driver_vs_reference(tmp_path):
+    """C++ restatement of test/specular_boundary_test.cpp vs the unmodified main"""
+    g = golden("sbt_51x51.npz")
+    k = list(g["steps"]).index(1000)
+    run("specular_boundary_test", "--T", 1000, "--dump", tmp_path / "sbt")
+    f = np.fromfile(tmp_path / "sbt-f.f64").reshape(51, 51, 9)
+    assert relerr(f, g["fs"][..., k]) < 1e-12
+
+
+def test_gravity_driver_vs_reference(tmp_path):
+    """C++ restatement of test/gravity_test.cpp: same early exit (t = 8301) and final state"""
+    g = golden("gt_21x21.npz")
+    out = run("gravity_test", "--dump", tmp_path / "gt")
+    assert int(out["steps"]) == int(g["last_t"]) == 8301
+    f = np.fromfile(tmp_path / "gt-f.f64").reshape(21, 21, 9)
+    assert relerr(f, g["fs"][..., -1]) < 1e-11
+    u = np.fromfile(tmp_path / "gt-u.f64").reshape(21, 21, 2)
+    assert relerr(u[..., 0], g["ux"][..., -1]) < 1e-10
+
+
+def test_free_stream_driver_vs_oracle(tmp_path, oracle):
+    (tmp_path / "p.toml").write_text(
+        "[flow]\ninitial_density = 1e3\nkinematic_viscosity = 1.0E-6\ncharacteristic_length = 2.2E-4\n"
+        "characteristic_velocity = 0.2\n[lattice]\nrelaxation_time = 0.6\nlattice_spacing = 2.0E-5\n"
+        "x_multiplier = 6\ny_multiplier = 4\n[simulation]\nstop_time = 1.0\nsnapshot_period = 1.0\n"
+        'file_prefix = "t-"\n')
+    run("free_stream_test", tmp_path / "p.toml", "--steps", 50, "--dump", tmp_path / "fs")
+    X, Y = 66, 44                                           # l = 11 -> 6*11, 4*11
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = 0.1
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+    fo, uo, rhoo = oracle.free_stream_steps(f0, 1.0 / 0.6, 0.1, 50)
+    f = np.fromfile(tmp_path / "fs-f.f64").reshape(X, Y, 9)
+    assert relerr(f, fo) < 1e-13

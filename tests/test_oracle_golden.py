@@ -128,3 +128,35 @@ def test_oracle_against_live_reference(oracle, ref):
     assert all(relerr(x, y) < 1e-12 for x, y in zip(a, b))
     psi = rng.standard_normal((R, C))
     assert relerr(oracle.diff_x(psi), ref.diff_x(psi)) < 1e-14
+
+
+def sbt_constants(H=51, W=51):
+    """test/specular_boundary_test.cpp:50-66"""
+    tau = np.sqrt(3.0 / 16.0) + 0.5
+    nu = (2.0 * tau - 1.0) / 6.0
+    p_grad = 8.0 * nu * 0.1 / (W * W)
+    return 1.0 / tau, 3.0 * (H - 1) * p_grad + 1.0, 1.0   # omega, rho_inlet, rho_outlet
+
+
+def test_specular_boundary_main(oracle):
+    """unmodified main of test/specular_boundary_test.cpp (51 x 51)."""
+    g = golden("sbt_51x51.npz")
+    omega, rin, rout = sbt_constants()
+    for k, t in enumerate(g["steps"]):
+        o = oracle.sbt_run(51, 51, int(t), omega, rin, rout)
+        assert relerr(o["f"], g["fs"][..., k]) < 1e-12, t
+    assert relerr(o["u"][..., 0], g["ux"][..., -1]) < 1e-10   # moments of iteration t-1
+
+
+def test_gravity_main(oracle):
+    """unmodified main of test/gravity_test.cpp (21 x 21, Fg = (-3e-4, 0)); it
+    stops by its own convergence rule at t = 8301."""
+    g = golden("gt_21x21.npz")
+    omega = 1.0 / (np.sqrt(3.0 / 16.0) + 0.5)
+    for k, t in enumerate(g["steps"][:-1]):
+        o = oracle.gravity_run(21, 21, int(t), omega, -0.0003, 0.0, check_convergence=False)
+        assert relerr(o["f"], g["fs"][..., k]) < 1e-12, t
+    full = oracle.gravity_run(21, 21, int(g["T"]), omega, -0.0003, 0.0, check_convergence=True)
+    assert full["steps"] == int(g["last_t"]) == 8301           # same early exit as the reference
+    assert relerr(full["f"], g["fs"][..., -1]) < 1e-11
+    assert relerr(full["u"][..., 0], g["ux"][..., -1]) < 1e-10
