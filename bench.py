@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--x2", type=int, default=1,
                     help="1 (default): temporal blocking, two time steps per launch; 0: one step per launch")
     ap.add_argument("--tb-rows", type=int, default=8, help="tile height of the two-step kernel")
+    ap.add_argument("--xn", type=int, default=5,
+                    help="D >= 2 (default 5): register sliding-window kernel, D time steps per launch; "
+                         "0: fall back to --x2 / single-step launches")
+    ap.add_argument("--sw-rows", type=int, default=64, help="rows per wavefront chunk of the sliding-window kernel")
+    ap.add_argument("--edge-rows", type=int, default=32, help="rows at each slab end computed ahead of the halo exchange")
     ap.add_argument("--force-halo", action="store_true",
                     help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv)")
     a = ap.parse_args()
@@ -125,10 +130,12 @@ def main():
 
     R, C = a.rows, a.cols
     prm = pylbm.BgkParams(a.omega, 0)
-    use_x2 = bool(a.x2) and C % 64 == 0 and R % a.tb_rows == 0 and R >= 4 * a.tb_rows
+    use_xn = a.xn >= 2 and C >= 64 and R >= max(4 * a.xn + 8, 4 * a.edge_rows)
+    use_x2 = (not use_xn) and bool(a.x2) and C % 64 == 0 and R % a.tb_rows == 0 and R >= 4 * a.tb_rows
     lib.set_tuning(b"tb_rows", a.tb_rows)
+    lib.set_tuning(b"sw_rows", a.sw_rows)
     ring = SlabRing(lib, R, C, rank, world, dev, periodic=True, plane_pad=a.plane_pad,
-                    force_ghost=a.force_halo, depth=2 if use_x2 else 1)
+                    force_ghost=a.force_halo, depth=a.xn if use_xn else (2 if use_x2 else 1))
     f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
     ring.load_precollision(f0, lambda dst, src, geom: lib.bgk_collide(
         _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring.stream_ptr()))
@@ -142,9 +149,18 @@ def main():
         lib.bgk_stream_collide_x2(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
                                   r0, r1, ring.stream_ptr())
 
+    def step_rows_xn(dst, src, geom, bc, r0, r1):
+        lib.bgk_stream_collide_xn(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
+                                  a.xn, r0, r1, ring.stream_ptr())
+
     def advance(n):
         """n time steps: pairs through the two-step kernel, a trailing odd one singly"""
-        if use_x2:
+        if use_xn:
+            for _ in range(n // a.xn):
+                ring.step(step_rows_xn, edge_rows=a.edge_rows)
+            for _ in range(n % a.xn):
+                ring.step(step_rows)
+        elif use_x2:
             for _ in range(n // 2):
                 ring.step(step_rows_x2, edge_rows=a.tb_rows)
             if n % 2:
@@ -154,7 +170,9 @@ def main():
                 ring.step(step_rows)
 
     # picks the overlap schedule (no-op without ghost rows)
-    if use_x2:
+    if use_xn:
+        ring.autotune(step_rows_xn, edge_rows=a.edge_rows)
+    elif use_x2:
         ring.autotune(step_rows_x2, edge_rows=a.tb_rows)
     else:
         ring.autotune(step_rows)
@@ -185,12 +203,13 @@ def main():
 
     if rank == 0:
         lups = R * C * world * a.steps / dt
-        steps_per_launch = 2 if use_x2 else 1
-        launches = a.steps // 2 + a.steps % 2 if use_x2 else a.steps
+        steps_per_launch = a.xn if use_xn else (2 if use_x2 else 1)
+        launches = a.steps // steps_per_launch + a.steps % steps_per_launch
         kern_ms = dev_ms / launches                      # avg duration of one launch
         alg_bytes = R * C * BYTES_PER_LUP * steps_per_launch   # algorithmic bytes one launch stands for
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        kernel = (f"k_stream_collide_tb2<BgkModel,{a.tb_rows},512,nt>" if use_x2
+        kernel = (f"k_stream_collide_sw<BgkModel,{a.xn},4,nt>" if use_xn else
+                  f"k_stream_collide_tb2<BgkModel,{a.tb_rows},512,nt>" if use_x2
                   else "k_stream_collide_v3<BgkModel,256,1,nt,nt>")
         # HBM bytes per launch cannot be read live (PMC counters need rocprofv3); report the figure
         # of the committed profile of this very kernel/config when there is one, else null
@@ -209,13 +228,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{R}x{C} D2Q9 BGK periodic box per GPU, Taylor-Green init, "
                                    f"fused collide+stream (pull, two SoA lattices"
-                                   f"{', 2 time steps per launch through an LDS tile' if use_x2 else ''}), omega={a.omega}",
+                                   f"{f', {a.xn} time steps per launch (register sliding window)' if use_xn else ', 2 time steps per launch through an LDS tile' if use_x2 else ''}), omega={a.omega}",
                        "rows_per_gpu": R, "cols": C, "global_rows": R * world,
                        "plane_pad_doubles": ring.plane - (R + 2 * ring.ghost) * C,
                        "parallelism": f"slab{world}" if world > 1 else "single",
                        "halo": ("none" if not ring.ghost else
-                                "9 rows of C doubles per side per 2 steps over RCCL send/recv" if ring.ghost == 2
-                                else "3 rows of C doubles per side per step over RCCL send/recv"),
+                                f"{9 * (ring.ghost - 1) if ring.ghost > 1 else 3} rows of C doubles per side per "
+                                f"{ring.ghost} step(s) over RCCL send/recv"),
                        "overlap_schedule": ring.schedule if ring.ghost else None,
                        "schedule_ms": getattr(ring, "autotune_ms", None)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -83,9 +83,9 @@ typedef struct lbm_geom {
   int R;     /* rows owned by this block / slab (reference dim 0, pairs with c_x) */
   int C;     /* columns (reference dim 1, pairs with c_y) */
   int ghost; /* 0: planes are [R][C] and streaming wraps rows periodically inside the block
-                g = 1, 2 or 3: planes are [R+2g][C]; rows -g..-1 and R..R+g-1 are ghost rows
-                owned by the neighbouring slabs (1: one step per launch; 2: two-step launches;
-                3: the colour-gradient step) */
+                g >= 1: planes are [R+2g][C]; rows -g..-1 and R..R+g-1 are ghost rows owned by the
+                neighbouring slabs (1: one step per launch; n: n-step launches; 3: the
+                colour-gradient step) */
   long long plane_stride; /* doubles between consecutive population planes; 0 = dense
                              ((R + 2*ghost) * C).  Padding it off a power of two spreads the 18
                              concurrent streams of the fused step over the HBM channels. */
@@ -115,6 +115,18 @@ typedef struct lbm_bc {
   double rho_inlet, rho_outlet;
   double uw_r, uw_c; /* wall velocity of LBM_EDGE_ABB_VELOCITY rows (u_w, cylinder_test.cpp:73) */
 } lbm_bc;
+
+/* ---- slab halo (multi-GPU): pack the rows a neighbour needs into ONE contiguous message -------
+ * depth = ghost rows in use (1: one step per launch, n: n-step launches, 3: colour gradient).
+ * Message = lbm_halo_rows(depth) rows of C doubles: 3 for depth 1, else 9 (depth - 1)
+ * (the block binding of test/decompose_domain.cpp:181-187 generalised).
+ * pack  side 1: my last `depth` rows  -> message for the NEXT slab;  side 0: my first rows -> PREVIOUS.
+ * unpack side 0: message from the PREVIOUS slab -> ghost rows above row 0;  side 1: from NEXT -> below. */
+int lbm_halo_rows(int depth);
+int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
+                  lbm_stream_t s);
+int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int depth, int side,
+                    lbm_stream_t s);
 
 /* ---- BGK (solver.cpp:23-74 fused with :76-131) ---------------------------------------- */
 typedef struct lbm_bgk_params {
@@ -151,6 +163,13 @@ int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
 int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom* g,
                               const lbm_bc* bc, const lbm_bgk_params* prm, int row_begin,
                               int row_end, lbm_stream_t s);
+/* Deeper temporal blocking: p_new = n_steps (2..6) applications of the step in one launch with
+ * the register sliding-window kernel (a wavefront walks down a 64-column strip keeping the last
+ * three rows of every intermediate step in registers; no LDS).  One lattice read + one write per
+ * n_steps updates; bit-identical results.  Periodic or ghost-row edges (ghost = 0 or >= n_steps). */
+int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
+                              int row_begin, int row_end, lbm_stream_t s);
 /* f = stream(p) incl. boundary fix-ups == solver::advect + the driver's post-advect BCs. */
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s);
 

@@ -111,6 +111,25 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
                                   row_end, as_stream(s));
 }
 
+int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
+                              int row_begin, int row_end, lbm_stream_t s) {
+  int rc = check_bgk("lbm_bgk_stream_collide_xn", prm);
+  if (rc) return rc;
+  const char* fn = "lbm_bgk_stream_collide_xn";
+  if (!prm->force_mode) {  // compile-time model: no mode branches inside the unrolled window
+    const int key = (prm->incompressible ? 2 : 0) | (prm->delta_form ? 1 : 0);
+    switch (key) {
+      case 0: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
+      case 1: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
+      case 2: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<1, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
+      default: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<1, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
+    }
+  }
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
+  return launch_stream_collide_sw(fn, p_new, p_old, g, bc, m, n_steps, row_begin, row_end, as_stream(s));
+}
+
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s) {
   int rc = validate_geom_bc("lbm_stream", g, bc);
   if (rc) return rc;

@@ -104,11 +104,95 @@ __global__ __launch_bounds__(256) void k_collision(double* __restrict__ fc,
     fc[i] = (1.0 - omega) * f[i] + omega * fe[i];  // solver.cpp:73
 }
 
+// ---- halo pack / unpack ---------------------------------------------------------------------
+// The populations a neighbouring slab needs are whole rows of single planes (SoA); a depth-D
+// halo is 9(D-1) of them per side (3 for D = 1).  Sending them row by row costs one message
+// each (72 per step at D = 5: ~2 ms of host time and a ~1 ms RCCL kernel); packed, it is one
+// message per neighbour.
+struct HaloTable {
+  int n;             // rows in the message
+  short q[80];       // population of row i
+  short row[80];     // lattice row (owned-row index space; ghost rows negative / >= R) of row i
+};
+__global__ __launch_bounds__(256) void k_halo_copy(double* __restrict__ dst,
+                                                   const double* __restrict__ src, Geom g,
+                                                   HaloTable t, int to_buffer) {
+  const long n = (long)t.n * g.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int k = (int)(i / g.C), c = (int)(i % g.C);
+    const long o = t.q[k] * g.plane + g.at(t.row[k], c);
+    if (to_buffer) dst[i] = src[o];
+    else dst[o] = src[i];
+  }
+}
+
+// rows of the depth-D halo in message order.  side 1: towards the NEXT slab (c_x = +1 leave);
+// side 0: towards the PREVIOUS one.  sender = true: the owned rows to send; false: the ghost rows
+// to fill on the receiving side (the receiver's `side` is where the message comes FROM).
+static int halo_table(HaloTable& t, int depth, int side, bool sender, int R) {
+  static const short out_next[3] = {1, 5, 8}, out_prev[3] = {3, 6, 7}, rest[3] = {0, 2, 4};
+  t.n = 0;
+  for (int k = 0; k < depth; ++k) {
+    short pops[9];
+    int np = 0;
+    // message (towards next) carries, from the sender's k-th row from its end: all 9 (k <= D-3),
+    // c_x = 0 and outward (k = D-2), outward only (k = D-1)   [pylbm/slab.py _halo_table]
+    const bool towards_next = sender ? (side == 1) : (side == 0);
+    const short* outward = towards_next ? out_next : out_prev;
+    if (k <= depth - 3) {
+      for (short q = 0; q < 9; ++q) pops[np++] = q;
+    } else if (k == depth - 2) {
+      for (int j = 0; j < 3; ++j) pops[np++] = rest[j];
+      for (int j = 0; j < 3; ++j) pops[np++] = outward[j];
+    } else {
+      for (int j = 0; j < 3; ++j) pops[np++] = outward[j];
+    }
+    int row;
+    if (sender) row = (side == 1) ? R - 1 - k : k;
+    else row = (side == 0) ? -1 - k : R + k;
+    for (int j = 0; j < np; ++j) {
+      if (t.n >= 80) return -1;
+      t.q[t.n] = pops[j];
+      t.row[t.n] = (short)row;
+      ++t.n;
+    }
+  }
+  return t.n;
+}
+
 }  // namespace lbm
 
 using namespace lbm;
 
 extern "C" {
+
+int lbm_halo_rows(int depth) { return depth <= 1 ? 3 : 9 * (depth - 1); }
+
+int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
+                  lbm_stream_t s) {
+  LBM_REQUIRE(buf && lattice && g && depth >= 1 && depth <= 8 && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
+  LBM_REQUIRE(g->ghost >= depth && g->R >= depth && g->R < 32000, "lbm_halo_pack: ghost=%d R=%d vs depth %d", g->ghost, g->R, depth);
+  HaloTable t;
+  LBM_REQUIRE(halo_table(t, depth, side, true, g->R) > 0, "lbm_halo_pack: depth too large");
+  const Geom gg = make_geom(*g);
+  LBM_KLAUNCH(k_halo_copy, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, 1024)), dim3(256), 0, as_stream(s),
+              buf, lattice, gg, t, 1);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int depth, int side,
+                    lbm_stream_t s) {
+  LBM_REQUIRE(buf && lattice && g && depth >= 1 && depth <= 8 && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
+  LBM_REQUIRE(g->ghost >= depth && g->R >= depth && g->R < 32000, "lbm_halo_unpack: ghost=%d R=%d vs depth %d", g->ghost, g->R, depth);
+  HaloTable t;
+  LBM_REQUIRE(halo_table(t, depth, side, false, g->R) > 0, "lbm_halo_unpack: depth too large");
+  const Geom gg = make_geom(*g);
+  LBM_KLAUNCH(k_halo_copy, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, 1024)), dim3(256), 0, as_stream(s),
+              lattice, buf, gg, t, 0);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
 
 const char* lbm_last_error_string(void) { return g_err; }
 int lbm_abi_version(void) { return 1; }

@@ -207,6 +207,33 @@ struct BgkModel {
   }
 };
 
+// Compile-time specialisation of the force-free BGK model (same arithmetic, no runtime mode
+// branches): shrinks the deeply unrolled multi-step kernels.
+template <int INCOMP, int DELTA>
+struct BgkModelT {
+  double omega;
+  __device__ __forceinline__ void collide(double (&f)[Q], double& rho, double& ux, double& uy) const {
+    double jx, jy, e[Q];
+    BgkModel::moments(f, rho, jx, jy);
+    if (INCOMP) {
+      ux = jx;
+      uy = jy;
+      BgkModel::feq_incomp(e, rho, ux, uy);
+    } else {
+      ux = jx / rho;
+      uy = jy / rho;
+      BgkModel::feq_comp(e, rho, ux, uy);
+    }
+    if (DELTA) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = f[q] + (-omega * (f[q] - e[q]));
+    } else {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = (1.0 - omega) * f[q] + omega * e[q];
+    }
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 // Kernels
 // ---------------------------------------------------------------------------------------
@@ -435,6 +462,152 @@ __global__ __launch_bounds__(BLOCK) void k_stream_collide_tb2(
       if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
       else *dst = f[q];
     }
+  }
+}
+
+// Temporal blocking, register sliding window: D time steps per launch, no LDS, no barriers.
+// One WAVEFRONT owns a strip of 64 columns and walks down a chunk of rows.  Per iteration it
+//   level 1 : pull-streams ONE new row from global memory (9 coalesced 512-B loads, prefetched
+//             one iteration ahead) and collides it,
+//   level l : pull-streams row (r - l + 1) of step t+l from the last three rows of step t+l-1,
+//             which it keeps in REGISTERS (ring[l-2][3][9]); the +-1-column neighbours come from
+//             the adjacent lanes by wave shuffles,
+//   level D : stores its row.
+// Every lattice row is read once and written once per D steps; the only redundancy is the
+// (D-1)-column overlap on each side of a strip (valid output columns per wave: 64 - 2(D-1)) and
+// 2(D-1) warm-up rows per row chunk.  Arithmetic per node and step is the single-step arithmetic:
+// bit-identical results.  The row loop is unrolled by 3 so that every ring index is static.
+// Periodic or ghost-row (ghost >= D) edges only.
+// value of the neighbouring lane: DPP wavefront shifts (one v_mov_b32_dpp per dword, no LDS
+// crossbar traffic) -- gfx9-family wave_shr:1 / wave_shl:1.  Edge lanes keep their own value;
+// they are outside the valid column range of the level that consumes them.
+#ifndef LBM_SW_DPP
+#define LBM_SW_DPP 1
+#endif
+__device__ __forceinline__ double lane_from_prev(double v) {  // lane i <- lane i-1
+#if LBM_SW_DPP
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#else
+  return __shfl_up(v, 1);
+#endif
+}
+__device__ __forceinline__ double lane_from_next(double v) {  // lane i <- lane i+1
+#if LBM_SW_DPP
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+#else
+  return __shfl_down(v, 1);
+#endif
+}
+
+template <class Model, int D, int K, bool NT_STORE>
+__device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3][Q], double (&cur)[Q],
+                                             double* __restrict__ pn, const double* __restrict__ po,
+                                             const Geom& g, const Model& m, int i, int rbase, int R0,
+                                             int R1, int c_load, const int (&cols)[3], bool lane_ok,
+                                             int c_out) {
+  // ---- prefetch level-1 inputs of the NEXT iteration -----------------------------------------
+  double nxt[Q];
+  {
+    const int r1n = rbase + i + 1;
+    int rr[3] = {r1n + 1, r1n, r1n - 1};  // rows supplying cx = -1, 0, +1
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (g.ghost) rr[k] = rr[k] < -g.ghost ? -g.ghost : (rr[k] > g.R + g.ghost - 1 ? g.R + g.ghost - 1 : rr[k]);
+      else rr[k] = rr[k] < 0 ? rr[k] + g.R : (rr[k] >= g.R ? rr[k] - g.R : rr[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) nxt[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
+  }
+  // ---- level 1 ---------------------------------------------------------------------------------
+  double f[Q], rho, ux, uy;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) f[q] = cur[q];
+  m.collide(f, rho, ux, uy);
+  // ---- levels 2..D -------------------------------------------------------------------------------
+#pragma unroll
+  for (int l = 2; l <= D; ++l) {
+    // publish level l-1's row of this iteration, then gather level l's row from the ring:
+    // cx = -1 pops from the row just computed (slot K), cx = 0 from the previous iteration's row
+    // (slot K+2), cx = +1 from the one before (slot K+1); cy = +-1 via the neighbouring lanes.
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ring[l - 2][K][q] = f[q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int slot = icx(q) == -1 ? K : (icx(q) == 0 ? (K + 2) % 3 : (K + 1) % 3);
+      double v = ring[l - 2][slot][q];
+      if (icy(q) == 1) v = lane_from_prev(v);        // from column c-1
+      else if (icy(q) == -1) v = lane_from_next(v);  // from column c+1
+      f[q] = v;
+    }
+    m.collide(f, rho, ux, uy);
+  }
+  // ---- store level D's row -------------------------------------------------------------------------
+  const int rD = rbase + i - (D - 1);  // level D's row = level 1's row - (D-1)
+  if (lane_ok && rD >= R0 && rD < R1) {
+    const long o = g.at(rD, c_out);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      double* dst = pn + q * g.plane + o;
+      if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
+      else *dst = f[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
+  (void)c_load;
+}
+
+// Register budget (ring 54*(D-1) VGPRs + prefetch 18 + working set) -> waves per SIMD the kernel
+// is compiled for: D = 2: 4, D = 3: 3, D = 4, 5: 2, deeper: 1 (only enforced for 4-wave blocks).
+__host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 : (D == 3 ? 3 : (D <= 5 ? 2 : 1)); }
+template <class Model, int D, int WAVES, bool NT_STORE>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
+    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
+    int row_end, int rows_per_chunk, int strips, int n_waves) {
+  constexpr int W = 64 - 2 * (D - 1);  // valid output columns per wave
+  const int wave = blockIdx.x * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wave >= n_waves) return;
+  const int strip = wave % strips, chunk = wave / strips;
+  const int R0 = row_begin + chunk * rows_per_chunk;
+  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
+  // this lane's column at every level; lanes D-1 .. 63-(D-1) hold valid level-D values
+  int c = strip * W - (D - 1) + lane;
+  const bool lane_ok = lane >= D - 1 && lane <= 63 - (D - 1) && c < g.C;
+  c = c < 0 ? c + g.C : (c >= g.C ? c - g.C : c);
+  c = c >= g.C ? c - g.C : c;  // last strip may run more than one period past the edge
+  const int cols[3] = {wrap_col(g, c + 1), c, wrap_col(g, c - 1)};
+  // level 1 at iteration i computes row rbase + i; level D's row = rbase + i - (D-1); the first
+  // valid level-D row (all inputs warmed up) appears at i = 2(D-1) and must be R0
+  const int rbase = R0 - (D - 1);
+  const int n_iter = (R1 - R0) + 2 * (D - 1);
+  double ring[D > 1 ? D - 1 : 1][3][Q];
+#pragma unroll
+  for (int a = 0; a < (D > 1 ? D - 1 : 1); ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) ring[a][b][q] = 1.0;  // warm-up garbage, never stored
+  double cur[Q];
+  {  // level-1 inputs of iteration 0
+    int rr[3] = {rbase + 1, rbase, rbase - 1};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (g.ghost) rr[k] = rr[k] < -g.ghost ? -g.ghost : (rr[k] > g.R + g.ghost - 1 ? g.R + g.ghost - 1 : rr[k]);
+      else rr[k] = rr[k] < 0 ? rr[k] + g.R : (rr[k] >= g.R ? rr[k] - g.R : rr[k]);
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) cur[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
+  }
+  for (int i = 0; i < n_iter; i += 3) {
+    sw_iteration<Model, D, 0, NT_STORE>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c);
+    sw_iteration<Model, D, 1, NT_STORE>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c);
+    sw_iteration<Model, D, 2, NT_STORE>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c);
   }
 }
 

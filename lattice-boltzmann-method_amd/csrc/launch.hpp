@@ -9,7 +9,7 @@ namespace lbm {
 inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc) {
   LBM_REQUIRE(g, "%s: NULL geometry", fn);
   LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
-  LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 3, "%s: ghost=%d must be 0..3", fn, g->ghost);
+  LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 8, "%s: ghost=%d must be 0..8", fn, g->ghost);
   LBM_REQUIRE(g->plane_stride == 0 || g->plane_stride >= (long long)(g->R + 2 * g->ghost) * g->C,
               "%s: plane_stride=%lld smaller than a plane", fn, g->plane_stride);
   if (bc) {
@@ -149,6 +149,48 @@ int launch_stream_collide_x2(const char* fn, double* pn, const double* po, const
     return LBM_ERR_INVALID;
   }
 #undef LBM_TB2
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+// p_new = D steps from p_old with the register sliding-window kernel; rows [row_begin, row_end)
+template <class Model>
+int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const lbm_geom* lg,
+                             const lbm_bc* lbc, const Model& m, int depth, int row_begin,
+                             int row_end, hipStream_t st) {
+  int rc = validate_geom_bc(fn, lg, lbc);
+  if (rc) return rc;
+  LBM_REQUIRE(pn && po && pn != po, "%s: NULL or aliased lattices", fn);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R,
+              "%s: row range [%d, %d) outside [0, %d)", fn, row_begin, row_end, lg->R);
+  const Bc bc = make_bc(lbc);
+  LBM_REQUIRE(!bc_needs_edge_pass(bc) && !bc.pressure_rows,
+              "%s: multi-step launches support periodic / halo edges only", fn);
+  LBM_REQUIRE(depth >= 2 && depth <= 6, "%s: %d steps per launch (supported: 2..6)", fn, depth);
+  LBM_REQUIRE(lg->ghost == 0 || lg->ghost >= depth, "%s: ghost=%d rows, need 0 or >= %d", fn, lg->ghost, depth);
+  LBM_REQUIRE(lg->R >= 4 * depth + 8 && lg->C >= 64, "%s: lattice %dx%d too small for %d-step launches", fn, lg->R, lg->C, depth);
+  if (row_begin == row_end) return LBM_OK;
+  const Geom g = make_geom(*lg);
+  const int nrows = row_end - row_begin;
+  int rpc = tuning("sw_rows", 256);
+  if (rpc > nrows) rpc = nrows;
+  const int W = 64 - 2 * (depth - 1);
+  const int strips = (g.C + W - 1) / W, chunks = (nrows + rpc - 1) / rpc;
+  const long n_waves_l = (long)strips * chunks;
+  LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
+  const int n_waves = (int)n_waves_l, nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", 4);
+#define LBM_SW(DV, WV)                                                                            \
+  if (depth == DV && waves == WV) {                                                               \
+    const dim3 grid((n_waves + WV - 1) / WV);                                                     \
+    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); \
+    else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves);   \
+  } else
+  LBM_SW(2, 4) LBM_SW(3, 4) LBM_SW(4, 4) LBM_SW(5, 4) LBM_SW(6, 4)
+  LBM_SW(2, 1) LBM_SW(3, 1) LBM_SW(4, 1) LBM_SW(2, 2) LBM_SW(3, 2) LBM_SW(4, 2) LBM_SW(5, 2) LBM_SW(6, 2) {
+    set_error("%s: no sliding-window instantiation for depth=%d sw_waves=%d", fn, depth, waves);
+    return LBM_ERR_INVALID;
+  }
+#undef LBM_SW
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }

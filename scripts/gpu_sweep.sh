@@ -7,7 +7,7 @@ out=gpurun_out/${2:-sweep}.log
 while IFS= read -r line; do
   [ -z "$line" ] && continue
   echo "== $line" >> $out
-  timeout -k 10 200 python bench.py --steps 60 --warmup 6 --no-cpu-baseline $line 2>&1 | grep -v amdgpu.ids >> $out || { echo "FAILED: $line" >> $out; exit 12; }
+  timeout -k 10 200 python bench.py --warmup 6 --no-cpu-baseline $line 2>&1 | grep -v amdgpu.ids >> $out || { echo "FAILED: $line" >> $out; exit 12; }
 done < "${1:-/dev/stdin}"
 python - "$out" <<'PY'
 import json, sys

@@ -323,6 +323,24 @@ def test_slab_ring_rccl_self_exchange(lib, oracle):
         lib.stream(_ptr(out), _ptr(p), ct.byref(pylbm.Geom(R, C, 0)), None, None)
         got = download_aos(lib, out)
         assert bits_equal(got, want2), ulp_diff(got, want2)
+
+        # depth 5: sliding-window launches, 36 halo rows per side per launch
+        want5, _, _ = oracle.bgk_periodic_steps(f0, 1.1, 1 + 5 * 4)
+        ring5 = SlabRing(lib, R, C, 0, 1, d, periodic=True, force_ghost=True, depth=5)
+        ring5.load_precollision(f0d, lambda dst, src, geom: lib.bgk_collide(
+            _ptr(dst), _ptr(src), ct.byref(geom), None, ct.byref(prm), None, None, ring5.stream_ptr()))
+
+        def step_rows_x5(dst, src, geom, bc, r0, r1):
+            lib.bgk_stream_collide_xn(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc),
+                                      ct.byref(prm), 5, r0, r1, ring5.stream_ptr())
+        ring5.autotune(step_rows_x5, steps=0, edge_rows=16)   # both schedules once: 2 launches
+        for _ in range(2):
+            ring5.step(step_rows_x5, edge_rows=16)
+        torch.cuda.synchronize()
+        p = ring5.owned().contiguous()
+        lib.stream(_ptr(out), _ptr(p), ct.byref(pylbm.Geom(R, C, 0)), None, None)
+        got = download_aos(lib, out)
+        assert bits_equal(got, want5), ulp_diff(got, want5)
     finally:
         dist.destroy_process_group()
 
@@ -404,3 +422,104 @@ def test_two_slabs_two_step_launches_equal_single_block(lib, oracle):
     lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
     got = download_aos(lib, out)
     assert bits_equal(got, want), ulp_diff(got, want)
+    # odd step count: one trailing SINGLE-step launch on the same depth-2 ghost geometry
+    # (what bench.py does when --steps is odd), edge rows = the ghost depth
+    for s in range(2):
+        src, dst = lat[s][cur], lat[s][cur ^ 1]
+        for r0, r1 in ((0, G), (R - G, R), (G, R - G)):
+            lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
+                                   r0, r1, None, None, None)
+    torch.cuda.synchronize()
+    cur ^= 1
+    halo(cur)
+    p = torch.cat([lat[0][cur][:, G:G + R], lat[1][cur][:, G:G + R]], dim=1).contiguous()
+    lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
+    want_odd, _, _ = oracle.bgk_periodic_steps(f0, 1.4, 2 + 2 * pairs)
+    got = download_aos(lib, out)
+    assert bits_equal(got, want_odd), ulp_diff(got, want_odd)
+
+
+@pytest.mark.parametrize("R,C", [(40, 128), (37, 64), (96, 200), (130, 256)])
+def test_sliding_window_temporal_blocking_bit_identical(lib, oracle, R, C):
+    """lbm_bgk_stream_collide_xn (register sliding window, D = 2..6 steps per launch) == D single
+    steps == oracle, bitwise; partial last strip (C not a multiple of the strip width), row
+    chunks that do not divide R, 1/2/4 waves per workgroup."""
+    f0 = random_state(oracle, R, C, seed=3 * R + C)
+    prm = pylbm.BgkParams(1.5, 0)
+    g = pylbm.Geom(R, C, 0)
+    f0d = upload_soa(lib, f0)
+    p0 = torch.empty((9, R, C), dtype=torch.float64, device=dev())
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(g), None, ct.byref(prm), None, None, None)
+    out = torch.empty_like(p0)
+    for depth, rows, waves in [(2, 256, 4), (3, 16, 4), (4, 11, 2), (5, 32, 2), (6, 256, 4), (2, 7, 1), (4, 256, 4)]:
+        lib.set_tuning(b"sw_rows", rows)
+        lib.set_tuning(b"sw_waves", waves)
+        a, b = p0.clone(), torch.empty_like(p0)
+        for _ in range(2):
+            lib.bgk_stream_collide_xn(_ptr(b), _ptr(a), ct.byref(g), None, ct.byref(prm), depth, 0, R, None)
+            a, b = b, a
+        lib.stream(_ptr(out), _ptr(a), ct.byref(g), None, None)
+        got = download_aos(lib, out)
+        want, _, _ = oracle.bgk_periodic_steps(f0, 1.5, 1 + 2 * depth)
+        assert bits_equal(got, want), (depth, rows, waves, ulp_diff(got, want))
+    lib.set_tuning(b"sw_rows", -1)
+    lib.set_tuning(b"sw_waves", -1)
+
+
+@pytest.mark.parametrize("depth", [3, 5])
+def test_two_slabs_sliding_window_launches_equal_single_block(lib, oracle, depth):
+    """D-step launches across a seam: 2 slabs with D ghost rows emulated on one GPU; halo per
+    launch = the 9(D-1) rows per side SlabRing(depth=D) sends; edge rows and interior rows launched
+    separately; a trailing single step on the same geometry.  Equals the single block bitwise."""
+    from pylbm.slab import HALO_TO_NEXT, HALO_TO_PREV
+    Rg, C, launches, E = 128, 128, 2, 16
+    R, G = Rg // 2, depth
+    f0 = random_state(oracle, Rg, C, seed=79 + depth)
+    prm = pylbm.BgkParams(1.4, 0)
+    flat = pylbm.Geom(Rg, C, 0)
+    p0 = torch.empty((9, Rg, C), dtype=torch.float64, device=dev())
+    f0d = upload_soa(lib, f0)
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(flat), None, ct.byref(prm), None, None, None)
+    torch.cuda.synchronize()
+    geom = pylbm.Geom(R, C, G)
+    bc = pylbm.Bc(row_lo=pylbm.EDGE_HALO, row_hi=pylbm.EDGE_HALO)
+    lat = [[torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=dev()) for _ in range(2)] for _ in range(2)]
+
+    def halo(cur):
+        for s in range(2):
+            o = 1 - s
+            for pops, k in HALO_TO_NEXT[depth]:
+                for q in pops:
+                    lat[o][cur][q, G - 1 - k] = lat[s][cur][q, G + R - 1 - k]
+            for pops, k in HALO_TO_PREV[depth]:
+                for q in pops:
+                    lat[o][cur][q, G + R + k] = lat[s][cur][q, G + k]
+
+    for s in range(2):
+        lat[s][0][:, G:G + R] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    lib.set_tuning(b"sw_rows", 24)
+    cur = 0
+    for _ in range(launches):
+        for s in range(2):
+            src, dst = lat[s][cur], lat[s][cur ^ 1]
+            for r0, r1 in ((0, E), (R - E, R), (E, R - E)):
+                lib.bgk_stream_collide_xn(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc),
+                                          ct.byref(prm), depth, r0, r1, None)
+        torch.cuda.synchronize()
+        cur ^= 1
+        halo(cur)
+    for s in range(2):   # one trailing single step
+        src, dst = lat[s][cur], lat[s][cur ^ 1]
+        for r0, r1 in ((0, G), (R - G, R), (G, R - G)):
+            lib.bgk_stream_collide(_ptr(dst), _ptr(src), ct.byref(geom), ct.byref(bc), ct.byref(prm),
+                                   r0, r1, None, None, None)
+    torch.cuda.synchronize()
+    cur ^= 1
+    p = torch.cat([lat[0][cur][:, G:G + R], lat[1][cur][:, G:G + R]], dim=1).contiguous()
+    out = torch.empty_like(p)
+    lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
+    got = download_aos(lib, out)
+    want, _, _ = oracle.bgk_periodic_steps(f0, 1.4, 1 + launches * depth + 1)
+    assert bits_equal(got, want), ulp_diff(got, want)
+    lib.set_tuning(b"sw_rows", -1)

@@ -66,6 +66,25 @@ def np_step_rows_x2(dst, src, geom, bc, r0, r1):
     d[:, g + r0: g + r1, :] = np_collide(f2)
 
 
+def np_step_rows_xn(depth):
+    """`depth` fused steps on rows [r0, r1) of the [9, R+2*depth, C] layout: level l is evaluated
+    on rows [r0-(depth-l), r1+(depth-l))."""
+    def fn(dst, src, geom, bc, r0, r1):
+        s, d = src.numpy(), dst.numpy()
+        g = geom.ghost
+        assert g >= depth
+        lo, hi = r0 - depth, r1 + depth          # rows of the current level's INPUT
+        cur = s[:, g + lo: g + hi, :]
+        for _ in range(depth):
+            n = cur.shape[1] - 2
+            f = np.empty((9, n, geom.C))
+            for q in range(9):
+                f[q] = np.roll(cur[q, 1 - CX[q]: 1 - CX[q] + n, :], CY[q], axis=1)
+            cur = np_collide(f)
+        d[:, g + r0: g + r1, :] = cur
+    return fn
+
+
 def worker(rank, world, port, R, C, steps, f0_path, out_path, depth=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -78,18 +97,13 @@ def worker(rank, world, port, R, C, steps, f0_path, out_path, depth=1):
     if depth == 1:
         for _ in range(steps - 1):  # n driver iterations = 1 collide + (n-1) fused steps
             ring.step(np_step_rows)
-    else:                           # pairs through the two-step path, a trailing odd one singly
-        def single(dst, src, geom, bc, r0, r1):   # one step on the ghost-2 layout
-            s_, d_ = src.numpy(), dst.numpy()
-            f = np.empty((9, r1 - r0, geom.C))
-            for q in range(9):
-                f[q] = np.roll(s_[q, 2 + r0 - CX[q]: 2 + r1 - CX[q], :], CY[q], axis=1)
-            d_[:, 2 + r0: 2 + r1, :] = np_collide(f)
+    else:                           # groups of `depth` fused steps, trailing ones singly
         n = steps - 1
-        for _ in range(n // 2):
-            ring.step(np_step_rows_x2, edge_rows=2)
-        if n % 2:
-            ring.step(single)
+        multi = np_step_rows_x2 if depth == 2 else np_step_rows_xn(depth)
+        for _ in range(n // depth):
+            ring.step(multi, edge_rows=depth)
+        for _ in range(n % depth):
+            ring.step(np_step_rows_xn(1))
     parts = [torch.empty_like(ring.owned().contiguous()) for _ in range(world)]
     dist.all_gather(parts, ring.owned().contiguous())
     if rank == 0:
@@ -98,9 +112,9 @@ def worker(rank, world, port, R, C, steps, f0_path, out_path, depth=1):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,depth,steps", [(2, 1, 9), (3, 1, 9), (2, 2, 9), (3, 2, 10)])
+@pytest.mark.parametrize("world,depth,steps", [(2, 1, 9), (3, 1, 9), (2, 2, 9), (3, 2, 10), (2, 5, 13), (3, 4, 11)])
 def test_slab_ring_equals_single_box(world, depth, steps, tmp_path, oracle):
-    R, C = 6, 16
+    R, C = (6 if depth <= 2 else 12), 16
     rng = np.random.default_rng(world)
     rho = 1 + 0.02 * rng.standard_normal((R * world, C))
     u = 0.05 * rng.standard_normal((R * world, C, 2))
