@@ -316,8 +316,11 @@ int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* 
  * produces bit-identical results).  Keys: "variant" (0 generic, 1 one node/thread grid-stride,
  * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0
  * non-temporal loads, bit 1 non-temporal stores; default 3), "block" (128..1024, default 256),
- * "rows" (rows per thread 1/2/4, default 1), "grid_cap" (variants 1-2).  value < 0 restores the
- * default.  Measurements: DESIGN.md "BGK kernel variants". */
+ * "rows" (rows per thread 1/2/4, default 1), "grid_cap" (variants 1-2); two-step LDS kernel:
+ * "tb_rows" (tile height, default 8), "tb_block" (default 512), "tb_order"; sliding-window kernel:
+ * "sw_rows" (rows per wavefront chunk, default 64), "sw_waves" (waves per workgroup, default 4);
+ * "solver_depth" (steps lbm_solver_step fuses per launch on periodic BGK blocks, default 5, 1 =
+ * off).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);
 int lbm_get_tuning(const char* key);
 

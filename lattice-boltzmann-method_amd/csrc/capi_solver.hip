@@ -149,9 +149,33 @@ int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host) {
   return LBM_OK;
 }
 
+// periodic BGK block without per-step observers: steps can be fused several per launch
+static bool solver_can_fuse_steps(const lbm_solver* sv) {
+  const lbm_bc& b = sv->bc;
+  auto plain = [](int m) { return m == LBM_EDGE_PERIODIC; };
+  return sv->model == LBM_MODEL_BGK && !sv->ibm && !b.pressure_rows && plain(b.row_lo) &&
+         plain(b.row_hi) && plain(b.col_lo) && plain(b.col_hi) && sv->g.C >= 64;
+}
+
 int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
   LBM_REQUIRE(sv && n >= 0, "lbm_solver_step: bad argument (n=%d)", n);
-  for (int i = 0; i < n; ++i) {
+  const int max_depth = tuning("solver_depth", 5);
+  for (int i = 0; i < n;) {
+    // temporal blocking: D driver iterations in one launch (bit-identical); the iteration that
+    // must record moments, and the first one on a pre-collision state, run singly
+    const int fusable = n - i - (record_moments ? 1 : 0);
+    int depth = fusable < max_depth ? fusable : max_depth;
+    while (depth >= 2 && sv->g.R < 4 * depth + 8) --depth;
+    if (sv->post && depth >= 2 && solver_can_fuse_steps(sv)) {
+      int rc = lbm_bgk_stream_collide_xn(sv->lat[sv->cur ^ 1], sv->lat[sv->cur], &sv->g, &sv->bc,
+                                         &sv->bgk, depth, 0, sv->g.R, sv->st);
+      if (rc) return rc;
+      sv->cur ^= 1;
+      sv->steps += depth;
+      i += depth;
+      continue;
+    }
+    {
     // with an immersed boundary every step needs this step's rho, u (cylinder_test.cpp:110)
     const bool rec = (record_moments && i == n - 1) || sv->ibm;
     int rc = sv->post ? solver_fused(sv, rec ? sv->rho : nullptr, rec ? sv->u : nullptr)
@@ -168,6 +192,8 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
     sv->post = true;
     if (rec) sv->have_moments = true;
     ++sv->steps;
+    ++i;
+    }
   }
   return LBM_OK;
 }

@@ -172,7 +172,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   if (row_begin == row_end) return LBM_OK;
   const Geom g = make_geom(*lg);
   const int nrows = row_end - row_begin;
-  int rpc = tuning("sw_rows", 256);
+  int rpc = tuning("sw_rows", 64);
   if (rpc > nrows) rpc = nrows;
   const int W = 64 - 2 * (depth - 1);
   const int strips = (g.C + W - 1) / W, chunks = (nrows + rpc - 1) / rpc;

@@ -12,7 +12,7 @@ timeout -k 10 600 python bench.py 2>&1 | grep -v amdgpu.ids | tee $O/bench_n1.js
 export TMPDIR=/tmp
 cd /tmp
 rm -rf $O/prof_kt $O/prof_fetch $O/prof_write
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/prof_kt.log 2>&1 || exit 13
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_kt -- python3 $R/bench.py --no-cpu-baseline > $O/prof_kt.log 2>&1 || exit 13
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_fetch.log 2>&1 || exit 14
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_write -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_write.log 2>&1 || exit 15
 cd $R

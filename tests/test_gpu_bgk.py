@@ -116,6 +116,7 @@ def test_interior_kernel_variants_bit_identical(lib, oracle, R, C):
     """Every tuning variant of the fused pull kernel == generic kernel == oracle, bitwise."""
     f0 = random_state(oracle, R, C, seed=R * 1000 + C)
     want, _, _ = oracle.bgk_periodic_steps(f0, 1.6, 7)
+    lib.set_tuning(b"solver_depth", 1)   # one step per launch: this test is about the single-step variants
     combos = [(0, 0, 0, 256, 1), (1, 0, 0, 256, 1), (2, 0, 0, 256, 1), (2, 3, 0, 256, 1),
               (1, 3, 0, 256, 1), (2, 1, 64, 256, 1), (2, 2, 7, 256, 1), (1, 0, 5, 256, 1),
               (3, 3, 0, 256, 1), (3, 0, 0, 128, 1), (3, 1, 0, 512, 2), (3, 2, 0, 1024, 1),
@@ -523,3 +524,21 @@ def test_two_slabs_sliding_window_launches_equal_single_block(lib, oracle, depth
     want, _, _ = oracle.bgk_periodic_steps(f0, 1.4, 1 + launches * depth + 1)
     assert bits_equal(got, want), ulp_diff(got, want)
     lib.set_tuning(b"sw_rows", -1)
+
+
+@pytest.mark.parametrize("n,record", [(2, False), (7, False), (7, True), (13, True), (23, False)])
+def test_solver_context_fuses_steps_transparently(lib, oracle, n, record):
+    """lbm_solver_step groups driver iterations into multi-step launches on periodic BGK blocks
+    (first iteration and the moment-recording one stay single): same results, bitwise."""
+    R, C = 72, 128
+    f0 = random_state(oracle, R, C, seed=n)
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, pylbm.BgkParams(1.3, 0))
+    sv.set_f(f0)
+    sv.step(n, record_moments=record)
+    got = sv.get_f()
+    want, rho_o, u_o = oracle.bgk_periodic_steps(f0, 1.3, n)
+    assert bits_equal(got, want), ulp_diff(got, want)
+    if record:
+        rho, u = sv.moments()
+        assert bits_equal(rho, rho_o) and bits_equal(u, u_o)
+    sv.close()
