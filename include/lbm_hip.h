@@ -205,9 +205,14 @@ typedef struct lbm_cg_colour {
 } lbm_cg_colour;
 typedef struct lbm_cg_params {
   lbm_cg_colour red, blue;
-  double sigma;   /* [general] sigma              (mrtcg_rayleigh_taylor.cpp:360) */
-  double gravity; /* [general] gravity_magnitude  (:361), Fg = (gravity, 0) along +r (:403) */
-  double delta;   /* interface half-width of the s_nu blend; the driver hard-codes 0.1 (:375) */
+  double sigma;     /* [general] sigma              (mrtcg_rayleigh_taylor.cpp:360) */
+  double gravity_r; /* Fg = (gravity_r, gravity_c): Rayleigh-Taylor driver ([general] gravity_magnitude, 0)
+                       (:361,:403); static-droplet driver (0, -6.25e-6) (mrtcg_static_droplet.cpp:452) */
+  double gravity_c;
+  int add_source;   /* 1: the source term built from Fg is added to both colours (:460-464);
+                       0: Fg only shifts the velocity, u += Fg/(2 rho) -- the static-droplet driver
+                       comments the source out (mrtcg_static_droplet.cpp:513-514) */
+  double delta;     /* interface half-width of the s_nu blend; the drivers hard-code 0.1 (:375) */
 } lbm_cg_params;
 /* differential::x (dir 0, d/d row) and ::y (dir 1, d/d column): isotropic 5x5 finite
  * differences with replicate padding (src/differential.hpp:9-40, src/differential.cpp:3-33);

@@ -99,7 +99,7 @@ void lbm_cg_default_bc(lbm_bc* bc) {
 int lbm_cg_equilibrium(double* f, const double* rho_k, const double* u, const lbm_cg_colour* k,
                        int R, int C, long long plane_stride, lbm_stream_t s) {
   LBM_REQUIRE(f && rho_k && u && k && R > 0 && C > 0, "lbm_cg_equilibrium: bad argument");
-  lbm_cg_params p{*k, *k, 0.0, 0.0, 0.1};
+  lbm_cg_params p{*k, *k, 0.0, 0.0, 0.0, 0, 0.1};
   const CgConsts cc = make_cg_consts(p);
   const long n = (long)R * C;
   LBM_REQUIRE(plane_stride == 0 || plane_stride >= n, "lbm_cg_equilibrium: plane_stride too small");
@@ -131,7 +131,7 @@ int lbm_cg_stream_moments(double* rho_r, double* rho_b, double* u, const double*
   const int lo = cg_row_lo(gg, bb), hi = cg_row_hi(gg, bb) + 1;  // incl. the macro ghost rows of a slab
   const long n = (long)(hi - lo) * gg.C;
   LBM_KLAUNCH(k_cg_stream_moments, dim3(capped_grid((n + 255) / 256, 8192)), dim3(256), 0, as_stream(s),
-              rho_r, rho_b, u, p_r, p_b, gg, bb, prm->gravity, make_macro_idx(gg), lo, hi);
+              rho_r, rho_b, u, p_r, p_b, gg, bb, prm->gravity_r, prm->gravity_c, make_macro_idx(gg), lo, hi);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }

@@ -24,7 +24,8 @@ struct CgColour {
 };
 struct CgConsts {
   CgColour k[2];  // 0 = red, 1 = blue
-  double sigma, g;
+  double sigma, gr, gc;  // Fg = (gr, gc)
+  int add_source;
   double delta, r_omega, b_omega, s1, s2, s3, t2, t3;  // relaxation_function :34-101
   double unitx[Q], unity[Q];                           // unit_E :176-178
 };
@@ -50,7 +51,9 @@ inline CgConsts make_cg_consts(const lbm_cg_params& p) {
     omega[i] = 1.0 / (0.5 + src[i]->nu / cs2);  // init_omega :57-58
   }
   c.sigma = p.sigma;
-  c.g = p.gravity;
+  c.gr = p.gravity_r;
+  c.gc = p.gravity_c;
+  c.add_source = p.add_source;
   c.delta = p.delta;
   c.r_omega = omega[0];
   c.b_omega = omega[1];
@@ -146,8 +149,8 @@ __host__ __device__ inline int cg_row_hi(const Geom& g, const Bc& bc) {  // incl
 // ---- pass A ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_cg_stream_moments(
     double* __restrict__ rho_r, double* __restrict__ rho_b, double* __restrict__ u,
-    const double* __restrict__ p_r, const double* __restrict__ p_b, Geom g, Bc bc, double grav,
-    MacroIdx mi, int row_lo, int row_hi /* exclusive */) {
+    const double* __restrict__ p_r, const double* __restrict__ p_b, Geom g, Bc bc, double grav_r,
+    double grav_c, MacroIdx mi, int row_lo, int row_hi /* exclusive */) {
   const long n = (long)(row_hi - row_lo) * g.C;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int r = row_lo + (int)(i / g.C), c = (int)(i % g.C);
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(256) void k_cg_stream_moments(
     const long o = mi.at(r, c);
     rho_r[o] = rr;
     rho_b[o] = rb;
-    u[o] = jx / rt + 0.5 * grav / rt;      // :477, Fg = (g, 0)
-    u[mi.n + o] = jy / rt + 0.5 * 0.0 / rt;
+    u[o] = jx / rt + 0.5 * grav_r / rt;      // :477  u + 0.5 Fg^T / rho
+    u[mi.n + o] = jy / rt + 0.5 * grav_c / rt;
   }
 }
 
@@ -293,11 +296,13 @@ __global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
     const double kappa = (rr * rb * gU * (rr * cc.k[0].phi[q] + rb * cc.k[1].phi[q])) /
                          ((rt * rt) * (1e-20 + gnorm));               // eval_kappa :302-318
     const double cu = ux * (double)icx(q) + uy * (double)icy(q);
-    const double FgE = cc.g * (double)icx(q) + 0.0 * (double)icy(q);
-    const double uFg = ux * cc.g + uy * 0.0;
+    const double FgE = cc.gr * (double)icx(q) + cc.gc * (double)icy(q);
+    const double uFg = ux * cc.gr + uy * cc.gc;
     const double Fq = (1 - 0.5 * s_nu) * ((3.0 + 9.0 * cu) * FgE - 3.0 * uFg) * wq(q);  // :460-462
-    pn_r[q * g.plane + lo] = (rr * tot[q] / rt + cc.k[0].beta * kappa) + Fq;  // :275-288, :463
-    pn_b[q * g.plane + lo] = (rb * tot[q] / rt + cc.k[1].beta * kappa) + Fq;  // :464
+    const double o3r = rr * tot[q] / rt + cc.k[0].beta * kappa;  // eval_rec_operator :275-288
+    const double o3b = rb * tot[q] / rt + cc.k[1].beta * kappa;
+    pn_r[q * g.plane + lo] = cc.add_source ? o3r + Fq : o3r;  // :463 (source commented out in
+    pn_b[q * g.plane + lo] = cc.add_source ? o3b + Fq : o3b;  // :464  mrtcg_static_droplet.cpp:513)
   }
   if (WITH_FIELDS) {
     const long oo = (long)r * g.C + c;  // diagnostics carry no ghost rows

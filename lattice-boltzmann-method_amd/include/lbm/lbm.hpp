@@ -310,11 +310,12 @@ namespace lbm {
 // two-phase driver loop (test/mrtcg_rayleigh_taylor.cpp:413-478), wraps lbm_cg_solver
 class CgSolver {
  public:
-  CgSolver(int R, int C, const colour& red, const colour& blue, double sigma, double gravity,
-           double delta = 0.1)
+  // Fg = (gravity_r, gravity_c); add_source = false: Fg only shifts u (static-droplet driver)
+  CgSolver(int R, int C, const colour& red, const colour& blue, double sigma, double gravity_r,
+           double delta = 0.1, double gravity_c = 0.0, bool add_source = true)
       : R_(R), C_(C) {
     lbm_geom g{R, C, 0, 0};
-    lbm_cg_params p{red.abi(), blue.abi(), sigma, gravity, delta};
+    lbm_cg_params p{red.abi(), blue.abi(), sigma, gravity_r, gravity_c, add_source ? 1 : 0, delta};
     check(lbm_cg_solver_create(&h_, &g, nullptr, &p, nullptr));
   }
   CgSolver(const CgSolver&) = delete;

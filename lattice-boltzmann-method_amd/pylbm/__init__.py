@@ -68,7 +68,8 @@ class CgColour(ct.Structure):
 
 class CgParams(ct.Structure):
     _fields_ = [("red", CgColour), ("blue", CgColour), ("sigma", ct.c_double),
-                ("gravity", ct.c_double), ("delta", ct.c_double)]
+                ("gravity_r", ct.c_double), ("gravity_c", ct.c_double), ("add_source", ct.c_int),
+                ("delta", ct.c_double)]
 
 
 class LbmError(RuntimeError):
@@ -198,10 +199,10 @@ class Solver:
 
 
 def cg_params(red=(3.0, 0.7, 0.04, 0.7), blue=(1.0, 0.1, 0.04, -0.7), sigma=0.1, gravity=6.25e-6,
-              delta=0.1):
+              delta=0.1, gravity_c=0.0, add_source=1):
     """[red]/[blue] of mrtcg-rayleigh-taylor-gamma3.toml as (rho_0, alpha, nu, beta); sigma and
     gravity are this build's recorded choices for the keys the shipped TOML lacks."""
-    return CgParams(CgColour(*red), CgColour(*blue), sigma, gravity, delta)
+    return CgParams(CgColour(*red), CgColour(*blue), sigma, gravity, gravity_c, add_source, delta)
 
 
 class CgSolver:

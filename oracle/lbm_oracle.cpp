@@ -715,6 +715,26 @@ void orc_cg_init(const orc_cg_params* p, double* f_r, double* f_b, double* rho_r
     }
 }
 
+void orc_cg_init_droplet(const orc_cg_params* p, double* f_r, double* f_b, double* rho_r,
+                         double* rho_b, double* u) {
+  const int R = p->R, C = p->C;
+  const colour_consts kr(p->red), kb(p->blue);
+  const double center = R / 2.0, radius = 25.0;  // mrtcg_static_droplet.cpp:188-189
+  auto sigmoid = [](double x) { return 1.0 / (1.0 + std::exp(-x)); };  // :180
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c < C; ++c) {
+      const double s = std::sqrt((r - center) * (r - center) + (c - center) * (c - center));
+      const size_t i = nid(r, c, C);
+      rho_r[i] = kr.rho_0 * (1.0 - sigmoid(1.0 * (s - radius)));  // invert = true  (:197)
+      rho_b[i] = kb.rho_0 * sigmoid(1.0 * (s - radius));          // :198
+      const double rho = rho_r[i] + rho_b[i];                      // :456
+      u[2 * i] = 0.0 + 0.5 * p->g_r / rho;                         // :457
+      u[2 * i + 1] = 0.0 + 0.5 * p->g_c / rho;
+      cg_feq(f_r + i * 9, rho_r[i], kr, u[2 * i], u[2 * i + 1]);  // :458-459
+      cg_feq(f_b + i * 9, rho_b[i], kb, u[2 * i], u[2 * i + 1]);
+    }
+}
+
 void orc_cg_steps(const orc_cg_params* p, double* f_r, double* f_b, double* rho_r, double* rho_b,
                   double* u, int nsteps, double* psi_out, double* snu_out, double* col_r_out,
                   double* col_b_out) {
@@ -723,7 +743,7 @@ void orc_cg_steps(const orc_cg_params* p, double* f_r, double* f_b, double* rho_
   small_grid_guard sg(N);
   const colour_consts kr(p->red), kb(p->blue);
   const relax_fn relax(kr, kb, p->delta);
-  const double g = p->gravity, sigma = p->sigma;
+  const double g_r = p->g_r, g_c = p->g_c, sigma = p->sigma;
   std::vector<double> rho(N), psi(N, 0.0), snu(N, 0.0), Qx(N), Qy(N), DxQx_r(N), DyQy_r(N),
       DxQx_b(N), DyQy_b(N), gx(N), gy(N), col_r(N * 9), col_b(N * 9);
   for (size_t i = 0; i < N; ++i) rho[i] = rho_r[i] + rho_b[i];  // :407 / :474
@@ -794,11 +814,13 @@ void orc_cg_steps(const orc_cg_params* p, double* f_r, double* f_b, double* rho_
                              ((rt * rt) * (1e-20 + gnorm));            // :302-318
         const double tot = f_r[i * 9 + q] + om1[0][q] + om2 + f_b[i * 9 + q] + om1[1][q] + om2;  // :455
         const double cu = ux * CX[q] + uy * CY[q];
-        const double FgE = g * CX[q] + 0.0 * CY[q];
-        const double uFg = ux * g + uy * 0.0;
+        const double FgE = g_r * CX[q] + g_c * CY[q];
+        const double uFg = ux * g_r + uy * g_c;
         const double Fq = (1 - 0.5 * s_nu) * ((3.0 + 9.0 * cu) * FgE - 3.0 * uFg) * W9[q];  // :460-462
-        cr[q] = (rr * tot / rt + kr.beta * kappa) + Fq;  // :275-288, :463
-        cb[q] = (rb * tot / rt + kb.beta * kappa) + Fq;  // :464
+        const double o3r = rr * tot / rt + kr.beta * kappa;  // :275-288
+        const double o3b = rb * tot / rt + kb.beta * kappa;
+        cr[q] = p->add_source ? o3r + Fq : o3r;  // :463 / mrtcg_static_droplet.cpp:513
+        cb[q] = p->add_source ? o3b + Fq : o3b;  // :464 / :514
       }
     }
     advect(f_r, col_r.data(), R, C);  // :466-467
@@ -816,8 +838,8 @@ void orc_cg_steps(const orc_cg_params* p, double* f_r, double* f_b, double* rho_
         jx += ft * CX[q];
         jy += ft * CY[q];
       }
-      u[2 * i] = jx / rho[i] + 0.5 * g / rho[i];
-      u[2 * i + 1] = jy / rho[i] + 0.5 * 0.0 / rho[i];
+      u[2 * i] = jx / rho[i] + 0.5 * g_r / rho[i];
+      u[2 * i + 1] = jy / rho[i] + 0.5 * g_c / rho[i];
     }
   }
   if (psi_out) std::memcpy(psi_out, psi.data(), N * sizeof(double));

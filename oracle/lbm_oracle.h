@@ -82,13 +82,20 @@ typedef struct {
 typedef struct {
   int R, C;
   orc_colour_params red, blue;
-  double sigma, gravity; /* [general] sigma, gravity_magnitude (:360-361) */
+  double sigma;          /* [general] sigma (:360); 0.1 hard-coded in mrtcg_static_droplet.cpp:439 */
+  double g_r, g_c;       /* Fg = (g_r, g_c): (gravity_magnitude, 0) (:361,:403) or (0, -6.25e-6) (droplet :452) */
+  int add_source;        /* 0: the droplet driver comments the source term out (:513-514) */
   double delta;          /* hard-coded 0.1 at :375 */
 } orc_cg_params;
 /* init_rho_cosine + feq init (:182-210, :372-373, :407-410): fills f_r, f_b (adv_f),
  * rho_r, rho_b, u (= 0). */
 void orc_cg_init(const orc_cg_params* p, double* f_r, double* f_b,
                  double* rho_r, double* rho_b, double* u);
+/* test/mrtcg_static_droplet.cpp:182-204, :420-421, :456-459: sigmoid droplet of radius 25 centred at
+ * (R/2, R/2) ("center" = R/2 is used for both coordinates), u = 0 + Fg/(2 rho) BEFORE the
+ * equilibrium initialisation. */
+void orc_cg_init_droplet(const orc_cg_params* p, double* f_r, double* f_b,
+                         double* rho_r, double* rho_b, double* u);
 /* nsteps iterations of the loop body :431-477. State in/out: adv_f of both colours,
  * rho_r, rho_b, u[R][C][2].  Optional outputs (may be NULL): psi, s_nu of the last step,
  * col_r/col_b = post-collision populations of the last step. */

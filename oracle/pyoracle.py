@@ -49,7 +49,8 @@ class ColourParams(ct.Structure):
 
 class CgParams(ct.Structure):
     _fields_ = [("R", ct.c_int), ("C", ct.c_int), ("red", ColourParams), ("blue", ColourParams),
-                ("sigma", ct.c_double), ("gravity", ct.c_double), ("delta", ct.c_double)]
+                ("sigma", ct.c_double), ("g_r", ct.c_double), ("g_c", ct.c_double),
+                ("add_source", ct.c_int), ("delta", ct.c_double)]
 
 
 class HptParams(ct.Structure):
@@ -63,10 +64,10 @@ class IbmMarkers(ct.Structure):
 
 
 def cg_params(R, C, red=(3.0, 0.7, 0.04, 0.7), blue=(1.0, 0.1, 0.04, -0.7), sigma=0.1,
-              gravity=6.25e-6, delta=0.1):
+              gravity=6.25e-6, delta=0.1, gravity_c=0.0, add_source=1):
     """Defaults: [red]/[blue] of mrtcg-rayleigh-taylor-gamma3.toml (rho_0, alpha, nu, beta);
     sigma/gravity are the builder's recorded choices."""
-    return CgParams(R, C, ColourParams(*red), ColourParams(*blue), sigma, gravity, delta)
+    return CgParams(R, C, ColourParams(*red), ColourParams(*blue), sigma, gravity, gravity_c, add_source, delta)
 
 
 def hpt_params(H=21, W=21, T=8301, check_convergence=1):
@@ -209,6 +210,14 @@ class Oracle:
                  rho_b=np.empty((R, C)), u=np.empty((R, C, 2)))
         self.lib.orc_cg_init(ct.byref(p), _p(s["f_r"]), _p(s["f_b"]), _p(s["rho_r"]),
                              _p(s["rho_b"]), _p(s["u"]))
+        return s
+
+    def cg_init_droplet(self, p):
+        R, C = p.R, p.C
+        s = dict(f_r=np.empty((R, C, 9)), f_b=np.empty((R, C, 9)), rho_r=np.empty((R, C)),
+                 rho_b=np.empty((R, C)), u=np.empty((R, C, 2)))
+        self.lib.orc_cg_init_droplet(ct.byref(p), _p(s["f_r"]), _p(s["f_b"]), _p(s["rho_r"]),
+                                     _p(s["rho_b"]), _p(s["u"]))
         return s
 
     def cg_steps(self, p, state, nsteps, want_col=False):

@@ -109,22 +109,31 @@ def apply_boundary_conditions(adv_f, col_f):  # :495-533
     adv_f[0, :, 1] = col_f[0, :, 3]; adv_f[0, :, 5] = col_f[0, :, 7]; adv_f[0, :, 8] = col_f[0, :, 6]
 
 
-def cg_run(R, C, red, blue, sigma, gravity, steps, delta=0.1):
-    """main() of test/mrtcg_rayleigh_taylor.cpp:364-477 for `steps` iterations."""
+def cg_run(R, C, red, blue, sigma, gravity, steps, delta=0.1, droplet=False):
+    """main() of test/mrtcg_rayleigh_taylor.cpp:364-477 for `steps` iterations; droplet=True: main()
+    of test/mrtcg_static_droplet.cpp:396-528 (sigmoid droplet, Fg = (0, gravity) shifts u only,
+    u shifted before the initial equilibrium, no source term; sigma = 0.1 there)."""
     r, b = Colour(*red, R, C), Colour(*blue, R, C)
     middle = R / 2.0  # init_rho_cosine :182-210
     for k, invert in ((r, True), (b, False)):
         for c in range(C):
             s = middle - 0.1 * C * math.cos(2.0 * 3.141592 * c / C)
             for rr in range(R):
-                ans = (1.0 if rr < s else 0.0) if invert else (1.0 if rr >= s else 0.0)
+                if droplet:  # init_rho_droplet, mrtcg_static_droplet.cpp:182-204
+                    d = math.sqrt((rr - middle) * (rr - middle) + (c - middle) * (c - middle))
+                    sg = 1.0 / (1.0 + math.exp(-(1.0 * (d - 25.0))))
+                    ans = 1.0 - sg if invert else sg
+                else:
+                    ans = (1.0 if rr < s else 0.0) if invert else (1.0 if rr >= s else 0.0)
                 k.rho[rr, c, 0] = k.rho_0 * ans
     relax = relaxation_function(r, b, delta)
     u = torch.zeros(R, C, 2)
     s_nu = torch.zeros(R, C)
     S = torch.diagflat(torch.tensor([0.0, 1.25, 1.14, 0.0, 1.6, 0.0, 1.6, 0.0, 0.0])).repeat(R, C, 1, 1)
-    Fg = torch.tensor([[gravity], [0.0]])
+    Fg = torch.tensor([[0.0], [gravity]]) if droplet else torch.tensor([[gravity], [0.0]])
     rho = r.rho + b.rho
+    if droplet:
+        u = u + 0.5 * Fg.t() / rho  # mrtcg_static_droplet.cpp:457
     r.adv_f = eval_equilibrium(r.rho, r.phi, r.eta, u)
     b.adv_f = eval_equilibrium(b.rho, b.phi, b.eta, u)
     phase = torch.zeros(R, C, 1)
@@ -153,7 +162,7 @@ def cg_run(R, C, red, blue, sigma, gravity, steps, delta=0.1):
         om3_r = r.rho * total_f / rho + r.beta * kappa
         om3_b = b.rho * total_f / rho + b.beta * kappa
         force = (1 - 0.5 * s_nu.unsqueeze(-1)) * ((3.0 + 9.0 * u.matmul(E)) * Fg.t().matmul(E) - 3.0 * u.matmul(Fg)) * W
-        r_col, b_col = om3_r + force, om3_b + force
+        r_col, b_col = (om3_r, om3_b) if droplet else (om3_r + force, om3_b + force)
         r.adv_f, b.adv_f = advect(r_col), advect(b_col)
         apply_boundary_conditions(r.adv_f, r_col)
         apply_boundary_conditions(b.adv_f, b_col)

