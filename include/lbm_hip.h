@@ -317,6 +317,24 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
  * that drive lbm_*_stream_collide themselves (benchmarks, multi-GPU slabs) */
 int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* geom /* may be NULL */);
 
+/* ---- snapshots and checkpoints (the reference only torch::save()s snapshot
+ * stacks at the end of a run, e.g. horizontal_poiseuille_test.cpp:157-160) ------------------------ */
+typedef struct lbm_snapshot lbm_snapshot;
+int lbm_snapshot_create(lbm_snapshot** out, lbm_solver* sv);
+int lbm_snapshot_destroy(lbm_snapshot* sn);
+/* capture the moments of the last lbm_solver_step(.., record_moments = 1): device staging on the
+ * solver's stream, device->pinned-host copy on a private stream; returns at once, the solver may
+ * keep stepping */
+int lbm_snapshot_record(lbm_snapshot* sn);
+/* wait for that copy; write rho [R,C] / u [R,C,2] as NumPy .npy (either path may be NULL) */
+int lbm_snapshot_write_npy(lbm_snapshot* sn, const char* rho_path, const char* u_path);
+/* wait for that copy; host pointers (valid until the next record) and the step they belong to */
+int lbm_snapshot_host(lbm_snapshot* sn, const double** rho, const double** u, long long* step);
+/* raw checkpoint of the resident lattice + state form + step counter + parameters; restart is
+ * bitwise.  load needs a solver of the same model and size. */
+int lbm_solver_checkpoint_save(lbm_solver* sv, const char* path);
+int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
+
 /* Tuning table for lbm_*_stream_collide's interior path (benchmarks / tests; every setting
  * produces bit-identical results).  Keys: "variant" (0 generic, 1 one node/thread grid-stride,
  * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0

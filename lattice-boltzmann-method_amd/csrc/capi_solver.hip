@@ -1,6 +1,11 @@
 // C ABI, part 3: solver context = the driver loop of the reference's test/*.cpp mains
 // (single block).  Model dispatch lives here; kernels are in d2q9.hpp / kbc.hpp.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
 #include <new>
+#include <string>
+#include <vector>
 
 #include "kbc.hpp"
 #include "launch.hpp"
@@ -239,6 +244,192 @@ int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* 
   *cur = sv->lat[sv->cur];
   *other = sv->lat[sv->cur ^ 1];
   if (geom) *geom = sv->g;
+  return LBM_OK;
+}
+
+}  // extern "C"
+
+// ---- snapshot / checkpoint I/O ----------------------------------------------
+// The reference keeps [R,C,n_snap] stacks on the host and torch::save()s them at the end
+// (e.g. horizontal_poiseuille_test.cpp:85-88,157-160).  Here a snapshot is an asynchronous
+// device->pinned-host copy of the recorded moments on a private stream (the solver keeps
+// stepping meanwhile) written as NumPy .npy; a checkpoint is the raw resident lattice plus the
+// solver's bookkeeping, restart is bitwise.
+struct lbm_snapshot {
+  lbm_solver* sv;
+  hipStream_t copy;
+  hipEvent_t ready, done;
+  double *d_rho, *d_u;   // device staging (AoS u)
+  double *h_rho, *h_u;   // pinned host
+  long step;
+};
+
+static int write_npy(const char* path, const double* data, const std::vector<long>& shape) {
+  std::string dict = "{'descr': '<f8', 'fortran_order': False, 'shape': (";
+  for (size_t i = 0; i < shape.size(); ++i) dict += std::to_string(shape[i]) + (shape.size() == 1 || i + 1 < shape.size() ? ", " : "");
+  dict += "), }";
+  size_t total = 10 + dict.size() + 1;
+  const size_t pad = (64 - total % 64) % 64;
+  dict += std::string(pad, ' ') + "\n";
+  FILE* f = std::fopen(path, "wb");
+  LBM_REQUIRE(f, "cannot open %s for writing", path);
+  const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+  const uint16_t hl = (uint16_t)dict.size();
+  size_t n = 1;
+  for (long d : shape) n *= (size_t)d;
+  bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(&hl, 2, 1, f) == 1 &&
+            std::fwrite(dict.data(), 1, dict.size(), f) == dict.size() &&
+            std::fwrite(data, sizeof(double), n, f) == n;
+  ok = (std::fclose(f) == 0) && ok;
+  LBM_REQUIRE(ok, "short write to %s", path);
+  return LBM_OK;
+}
+
+struct CheckpointHeader {
+  char magic[8];  // "LBMCKPT1"
+  int32_t model, R, C, post;
+  int64_t steps;
+  lbm_bc bc;
+  lbm_bgk_params bgk;
+  lbm_kbc_params kbc;
+};
+
+extern "C" {
+
+int lbm_snapshot_create(lbm_snapshot** out, lbm_solver* sv) {
+  LBM_REQUIRE(out && sv, "lbm_snapshot_create: NULL argument");
+  lbm_snapshot* sn = new (std::nothrow) lbm_snapshot();
+  LBM_REQUIRE(sn, "lbm_snapshot_create: out of host memory");
+  std::memset(sn, 0, sizeof *sn);
+  sn->sv = sv;
+  const size_t n = (size_t)sv->g.R * sv->g.C;
+  hipError_t e = hipStreamCreateWithFlags(&sn->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&sn->ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&sn->done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc(&sn->d_rho, n * 8);
+  if (e == hipSuccess) e = hipMalloc(&sn->d_u, n * 16);
+  if (e == hipSuccess) e = hipHostMalloc(&sn->h_rho, n * 8);
+  if (e == hipSuccess) e = hipHostMalloc(&sn->h_u, n * 16);
+  if (e != hipSuccess) {
+    set_error("lbm_snapshot_create: %s", hipGetErrorString(e));
+    lbm_snapshot_destroy(sn);
+    return LBM_ERR_HIP;
+  }
+  *out = sn;
+  return LBM_OK;
+}
+
+int lbm_snapshot_destroy(lbm_snapshot* sn) {
+  if (!sn) return LBM_OK;
+  if (sn->copy) (void)hipStreamSynchronize(sn->copy);
+  if (sn->d_rho) (void)hipFree(sn->d_rho);
+  if (sn->d_u) (void)hipFree(sn->d_u);
+  if (sn->h_rho) (void)hipHostFree(sn->h_rho);
+  if (sn->h_u) (void)hipHostFree(sn->h_u);
+  if (sn->ready) (void)hipEventDestroy(sn->ready);
+  if (sn->done) (void)hipEventDestroy(sn->done);
+  if (sn->copy) (void)hipStreamDestroy(sn->copy);
+  delete sn;
+  return LBM_OK;
+}
+
+// Capture the moments recorded by the last lbm_solver_step(.., record_moments = 1).  The staging
+// copy is ordered on the solver's stream (so later steps may overwrite rho/u at once); the
+// device->host transfer runs on the snapshot's own stream.  Returns immediately.
+int lbm_snapshot_record(lbm_snapshot* sn) {
+  LBM_REQUIRE(sn, "lbm_snapshot_record: NULL snapshot");
+  lbm_solver* sv = sn->sv;
+  if (!sv->have_moments) {
+    set_error("lbm_snapshot_record: no step(.., record_moments=1) since the last set_f");
+    return LBM_ERR_STATE;
+  }
+  const int R = sv->g.R, C = sv->g.C;
+  const size_t n = (size_t)R * C;
+  LBM_CHECK_HIP(hipStreamWaitEvent(sv->st, sn->done, 0));  // previous D2H of this snapshot finished
+  LBM_CHECK_HIP(hipMemcpyAsync(sn->d_rho, sv->rho, n * 8, hipMemcpyDeviceToDevice, sv->st));
+  int rc = lbm_soa_to_aos(sn->d_u, sv->u, R, C, 2, sv->st);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipEventRecord(sn->ready, sv->st));
+  LBM_CHECK_HIP(hipStreamWaitEvent(sn->copy, sn->ready, 0));
+  LBM_CHECK_HIP(hipMemcpyAsync(sn->h_rho, sn->d_rho, n * 8, hipMemcpyDeviceToHost, sn->copy));
+  LBM_CHECK_HIP(hipMemcpyAsync(sn->h_u, sn->d_u, n * 16, hipMemcpyDeviceToHost, sn->copy));
+  LBM_CHECK_HIP(hipEventRecord(sn->done, sn->copy));
+  sn->step = sv->steps;
+  return LBM_OK;
+}
+
+// Wait for the transfer and write rho [R,C] and u [R,C,2] as NumPy .npy files (either path may
+// be NULL).  The host pointers stay valid until the next record: lbm_snapshot_host().
+int lbm_snapshot_write_npy(lbm_snapshot* sn, const char* rho_path, const char* u_path) {
+  LBM_REQUIRE(sn, "lbm_snapshot_write_npy: NULL snapshot");
+  LBM_CHECK_HIP(hipStreamSynchronize(sn->copy));
+  const long R = sn->sv->g.R, C = sn->sv->g.C;
+  if (rho_path) {
+    int rc = write_npy(rho_path, sn->h_rho, {R, C});
+    if (rc) return rc;
+  }
+  if (u_path) return write_npy(u_path, sn->h_u, {R, C, 2});
+  return LBM_OK;
+}
+
+int lbm_snapshot_host(lbm_snapshot* sn, const double** rho, const double** u, long long* step) {
+  LBM_REQUIRE(sn, "lbm_snapshot_host: NULL snapshot");
+  LBM_CHECK_HIP(hipStreamSynchronize(sn->copy));
+  if (rho) *rho = sn->h_rho;
+  if (u) *u = sn->h_u;
+  if (step) *step = sn->step;
+  return LBM_OK;
+}
+
+int lbm_solver_checkpoint_save(lbm_solver* sv, const char* path) {
+  LBM_REQUIRE(sv && path, "lbm_solver_checkpoint_save: NULL argument");
+  const size_t n = (size_t)sv->g.R * sv->g.C;
+  std::vector<double> host(n * 9);
+  const size_t plane_bytes = n * sizeof(double);
+  LBM_CHECK_HIP(hipMemcpy2DAsync(host.data(), plane_bytes, sv->lat[sv->cur],
+                                 (size_t)sv->g.plane_stride * sizeof(double), plane_bytes, 9,
+                                 hipMemcpyDeviceToHost, sv->st));
+  LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  CheckpointHeader h;
+  std::memset(&h, 0, sizeof h);
+  std::memcpy(h.magic, "LBMCKPT1", 8);
+  h.model = sv->model; h.R = sv->g.R; h.C = sv->g.C; h.post = sv->post ? 1 : 0; h.steps = sv->steps;
+  h.bc = sv->bc; h.bgk = sv->bgk; h.kbc = sv->kbc;
+  FILE* f = std::fopen(path, "wb");
+  LBM_REQUIRE(f, "lbm_solver_checkpoint_save: cannot open %s", path);
+  bool ok = std::fwrite(&h, sizeof h, 1, f) == 1 && std::fwrite(host.data(), 8, host.size(), f) == host.size();
+  ok = (std::fclose(f) == 0) && ok;
+  LBM_REQUIRE(ok, "lbm_solver_checkpoint_save: short write to %s", path);
+  return LBM_OK;
+}
+
+// Restore lattice, state form and step counter into a solver created with the same model and size
+// (boundary set and parameters are taken from the file).
+int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path) {
+  LBM_REQUIRE(sv && path, "lbm_solver_checkpoint_load: NULL argument");
+  FILE* f = std::fopen(path, "rb");
+  LBM_REQUIRE(f, "lbm_solver_checkpoint_load: cannot open %s", path);
+  CheckpointHeader h;
+  const size_t n = (size_t)sv->g.R * sv->g.C;
+  std::vector<double> host(n * 9);
+  bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, "LBMCKPT1", 8) == 0;
+  if (ok && (h.model != sv->model || h.R != sv->g.R || h.C != sv->g.C)) {
+    std::fclose(f);
+    set_error("lbm_solver_checkpoint_load: %s holds model %d %dx%d, solver is model %d %dx%d", path,
+              h.model, h.R, h.C, sv->model, sv->g.R, sv->g.C);
+    return LBM_ERR_INVALID;
+  }
+  ok = ok && std::fread(host.data(), 8, host.size(), f) == host.size();
+  std::fclose(f);
+  LBM_REQUIRE(ok, "lbm_solver_checkpoint_load: %s is not a complete checkpoint", path);
+  const size_t plane_bytes = n * sizeof(double);
+  LBM_CHECK_HIP(hipMemcpy2DAsync(sv->lat[sv->cur], (size_t)sv->g.plane_stride * sizeof(double),
+                                 host.data(), plane_bytes, plane_bytes, 9, hipMemcpyHostToDevice, sv->st));
+  LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  sv->bc = h.bc; sv->bgk = h.bgk; sv->kbc = h.kbc;
+  sv->post = h.post != 0;
+  sv->steps = h.steps;
+  sv->have_moments = false;
   return LBM_OK;
 }
 

@@ -187,6 +187,12 @@ class Solver:
     def sync(self):
         self.lib.solver_sync(self.h)
 
+    def checkpoint_save(self, path):
+        self.lib.solver_checkpoint_save(self.h, str(path).encode())
+
+    def checkpoint_load(self, path):
+        self.lib.solver_checkpoint_load(self.h, str(path).encode())
+
     def attach_ibm(self, ibm, guo_a=1.0 / 3.0, guo_b=1.0 / 9.0):
         """defaults: the (1/3, 1/9) the cylinder driver uses (cylinder_test.cpp:66-67)"""
         self._ibm = ibm  # keep alive
