@@ -317,6 +317,26 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
  * that drive lbm_*_stream_collide themselves (benchmarks, multi-GPU slabs) */
 int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* geom /* may be NULL */);
 
+/* ---- slab ring in C++: one process per GPU, RCCL send/recv on packed halo buffers ------------------
+ * Native counterpart of pylbm/slab.py (same kernels, same halo sets): edge rows + pack + ONE
+ * ncclSend/ncclRecv pair per neighbour + unpack on the ring's own high-priority stream, interior rows
+ * on the caller's stream.  RCCL is dlopen()ed on first use.  Rank 0 calls lbm_ring_unique_id and
+ * distributes the 128 bytes by any means (file, MPI, torch.distributed); every rank then calls
+ * lbm_ring_create with its slab geometry (ghost = halo depth). */
+typedef struct lbm_ring lbm_ring;
+int lbm_ring_unique_id(unsigned char* id128);
+int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nranks,
+                    const lbm_geom* slab, int periodic);
+int lbm_ring_destroy(lbm_ring* rg);
+/* refresh the ghost rows of `lattice` (ordered after the work enqueued on `after`); asynchronous */
+int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after);
+/* make `main` wait for the ring's stream */
+int lbm_ring_join(lbm_ring* rg, lbm_stream_t main);
+/* one overlapped launch-step of a BGK slab: n_steps = 1 (single-step kernel) or 2..ghost (sliding
+ * window); bc: the physical edges of the GLOBAL domain (NULL = periodic), seams become HALO */
+int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                      const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
+
 /* ---- snapshots and checkpoints (the reference only torch::save()s snapshot
  * stacks at the end of a run, e.g. horizontal_poiseuille_test.cpp:157-160) ------------------------ */
 typedef struct lbm_snapshot lbm_snapshot;

@@ -1,0 +1,234 @@
+// C ABI, part 7: the slab ring in C++ -- one process per GPU, RCCL send/recv over xGMI on packed
+// halo buffers, overlapped with the interior launch on a second HIP stream.  This is the native
+// counterpart of pylbm/slab.py (which drives the same kernels through torch.distributed); both
+// implement the block binding of test/decompose_domain.cpp:181-187 generalised to D ghost rows.
+//
+// RCCL is dlopen()ed on first use (librccl.so of the hosting process if one is already mapped,
+// e.g. PyTorch's, else the ROCm one): liblbm_hip.so itself has no link-time dependency on it.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <new>
+
+#include "d2q9.hpp"
+#include "internal.hpp"
+
+namespace {
+
+// the slice of rccl.h this file needs (kept local so the build does not require the header)
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;            // ncclSuccess = 0
+const int kNcclFloat64 = 8;          // ncclDataType_t ncclFloat64 / ncclDouble
+
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.h) return LBM_OK;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    lbm::set_error("lbm_ring: cannot dlopen librccl.so (%s)", dlerror());
+    return LBM_ERR_HIP;
+  }
+#define LBM_SYM(field, name)                                                         \
+  *(void**)(&g_rccl.field) = dlsym(h, name);                                         \
+  if (!g_rccl.field) {                                                               \
+    lbm::set_error("lbm_ring: librccl.so lacks %s", name);                           \
+    return LBM_ERR_HIP;                                                              \
+  }
+  LBM_SYM(GetUniqueId, "ncclGetUniqueId")
+  LBM_SYM(CommInitRank, "ncclCommInitRank")
+  LBM_SYM(CommDestroy, "ncclCommDestroy")
+  LBM_SYM(Send, "ncclSend")
+  LBM_SYM(Recv, "ncclRecv")
+  LBM_SYM(GroupStart, "ncclGroupStart")
+  LBM_SYM(GroupEnd, "ncclGroupEnd")
+  LBM_SYM(GetErrorString, "ncclGetErrorString")
+#undef LBM_SYM
+  g_rccl.h = h;
+  return LBM_OK;
+}
+
+#define LBM_CHECK_NCCL(expr)                                                                  \
+  do {                                                                                        \
+    ncclResult_t r_ = (expr);                                                                 \
+    if (r_ != 0) {                                                                            \
+      lbm::set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+      return LBM_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+}  // namespace
+
+struct lbm_ring {
+  ncclComm_t comm;
+  int rank, nranks, next, prev;  // neighbours, -1 = none (chain end)
+  lbm_geom g;                    // slab geometry (ghost = halo depth)
+  size_t msg;                    // doubles per packed message
+  hipStream_t edge;              // edge rows, pack, send/recv, unpack
+  hipEvent_t main_done, edge_done;
+  double *send_next, *send_prev, *recv_prev, *recv_next;
+};
+
+using namespace lbm;
+
+extern "C" {
+
+int lbm_ring_unique_id(unsigned char* id128) {
+  LBM_REQUIRE(id128, "lbm_ring_unique_id: NULL buffer");
+  int rc = load_rccl();
+  if (rc) return rc;
+  ncclUniqueId id;
+  LBM_CHECK_NCCL(g_rccl.GetUniqueId(&id));
+  std::memcpy(id128, id.internal, 128);
+  return LBM_OK;
+}
+
+int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nranks,
+                    const lbm_geom* slab, int periodic) {
+  LBM_REQUIRE(out && id128 && slab, "lbm_ring_create: NULL argument");
+  LBM_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "lbm_ring_create: rank %d of %d", rank, nranks);
+  LBM_REQUIRE(slab->ghost >= 1 && slab->ghost <= 8, "lbm_ring_create: slab needs 1..8 ghost rows (ghost=%d)", slab->ghost);
+  int rc = load_rccl();
+  if (rc) return rc;
+  lbm_ring* rg = new (std::nothrow) lbm_ring();
+  LBM_REQUIRE(rg, "lbm_ring_create: out of host memory");
+  std::memset(rg, 0, sizeof *rg);
+  rg->rank = rank;
+  rg->nranks = nranks;
+  rg->next = (periodic || rank < nranks - 1) ? (rank + 1) % nranks : -1;
+  rg->prev = (periodic || rank > 0) ? (rank + nranks - 1) % nranks : -1;
+  rg->g = *slab;
+  rg->msg = (size_t)lbm_halo_rows(slab->ghost) * slab->C;
+  ncclUniqueId id;
+  std::memcpy(id.internal, id128, 128);
+  ncclResult_t nr = g_rccl.CommInitRank(&rg->comm, nranks, id, rank);
+  if (nr != 0) {
+    set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(nr));
+    delete rg;
+    return LBM_ERR_HIP;
+  }
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&rg->edge, hipStreamNonBlocking, hi);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->main_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->edge_done, hipEventDisableTiming);
+  for (double** p : {&rg->send_next, &rg->send_prev, &rg->recv_prev, &rg->recv_next})
+    if (e == hipSuccess) e = hipMalloc(p, rg->msg * sizeof(double));
+  if (e != hipSuccess) {
+    set_error("lbm_ring_create: %s", hipGetErrorString(e));
+    lbm_ring_destroy(rg);
+    return LBM_ERR_HIP;
+  }
+  *out = rg;
+  return LBM_OK;
+}
+
+int lbm_ring_destroy(lbm_ring* rg) {
+  if (!rg) return LBM_OK;
+  if (rg->edge) (void)hipStreamSynchronize(rg->edge);
+  for (double* p : {rg->send_next, rg->send_prev, rg->recv_prev, rg->recv_next})
+    if (p) (void)hipFree(p);
+  if (rg->main_done) (void)hipEventDestroy(rg->main_done);
+  if (rg->edge_done) (void)hipEventDestroy(rg->edge_done);
+  if (rg->edge) (void)hipStreamDestroy(rg->edge);
+  if (rg->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(rg->comm);
+  delete rg;
+  return LBM_OK;
+}
+
+// Bring the ghost rows of `lattice` up to date: pack, one send + one recv per neighbour in one
+// RCCL group, unpack -- all enqueued on the ring's edge stream, after the work already enqueued
+// on `after`.
+int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after) {
+  LBM_REQUIRE(rg && lattice, "lbm_ring_exchange: NULL argument");
+  const int G = rg->g.ghost;
+  if (as_stream(after) != rg->edge) {
+    LBM_CHECK_HIP(hipEventRecord(rg->main_done, as_stream(after)));
+    LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+  }
+  if (rg->next >= 0) {
+    int rc = lbm_halo_pack(rg->send_next, lattice, &rg->g, G, 1, rg->edge);
+    if (rc) return rc;
+  }
+  if (rg->prev >= 0) {
+    int rc = lbm_halo_pack(rg->send_prev, lattice, &rg->g, G, 0, rg->edge);
+    if (rc) return rc;
+  }
+  LBM_CHECK_NCCL(g_rccl.GroupStart());
+  // sends (to next, to prev), receives (from prev, from next): with two ranks both neighbours
+  // are the same peer and messages match in issue order
+  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_next, rg->msg, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_prev, rg->msg, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_prev, rg->msg, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_next, rg->msg, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  LBM_CHECK_NCCL(g_rccl.GroupEnd());
+  if (rg->prev >= 0) {
+    int rc = lbm_halo_unpack(lattice, rg->recv_prev, &rg->g, G, 0, rg->edge);
+    if (rc) return rc;
+  }
+  if (rg->next >= 0) {
+    int rc = lbm_halo_unpack(lattice, rg->recv_next, &rg->g, G, 1, rg->edge);
+    if (rc) return rc;
+  }
+  return LBM_OK;
+}
+
+// One launch-step of the BGK slab with overlap: edge rows (edge stream), interior rows (main
+// stream, concurrently), halo exchange of dst behind the edge rows.  n_steps = 1: single-step
+// kernel (ghost >= 1); n_steps >= 2: sliding-window kernel (ghost >= n_steps).  On return `main`
+// has been made to wait for everything: the next call may follow immediately.
+int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                      const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_bgk_step: NULL argument");
+  const int R = rg->g.R, G = rg->g.ghost;
+  LBM_REQUIRE(n_steps >= 1 && n_steps <= G, "lbm_ring_bgk_step: %d steps with %d ghost rows", n_steps, G);
+  if (edge_rows < G) edge_rows = G;
+  LBM_REQUIRE(2 * edge_rows < R, "lbm_ring_bgk_step: edge_rows=%d too large for %d rows", edge_rows, R);
+  hipStream_t main = as_stream(main_s);
+  lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
+  if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
+  if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  auto rows = [&](int r0, int r1, hipStream_t st) -> int {
+    if (n_steps == 1) return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
+    return lbm_bgk_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
+  };
+  // edge stream starts after everything previously enqueued on main (src complete)
+  LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
+  LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+  int rc = rows(0, edge_rows, rg->edge);
+  if (!rc) rc = rows(R - edge_rows, R, rg->edge);
+  if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
+  if (!rc) rc = lbm_ring_exchange(rg, dst, rg->edge);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+  LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+  return LBM_OK;
+}
+
+// make `main` wait for an exchange enqueued with lbm_ring_exchange (initial ghost fill)
+int lbm_ring_join(lbm_ring* rg, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg, "lbm_ring_join: NULL ring");
+  LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+  LBM_CHECK_HIP(hipStreamWaitEvent(as_stream(main_s), rg->edge_done, 0));
+  return LBM_OK;
+}
+
+}  // extern "C"

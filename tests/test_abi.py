@@ -42,3 +42,18 @@ def test_argument_validation_needs_no_gpu():
 def test_missing_library_fails_loudly(tmp_path):
     with pytest.raises(pylbm.LbmError, match="no CPU fallback"):
         pylbm.load_library(str(tmp_path / "nope.so"))
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/lbm_hip.h compiles as C99 (-pedantic -Werror) and links against liblbm_hip.so"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "c99.c"
+    src.write_text('#include "lbm_hip.h"\nint main(void){ lbm_geom g = {4,4,0,0}; lbm_bc b; '
+                   'lbm_cg_default_bc(&b); return lbm_abi_version() == 1 && g.R == 4 ? 0 : 1; }\n')
+    libdir = os.path.join(root, "lattice-boltzmann-method_amd", "lib")
+    exe = tmp_path / "c99"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           str(src), "-L", libdir, "-llbm_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0

@@ -542,3 +542,47 @@ def test_solver_context_fuses_steps_transparently(lib, oracle, n, record):
         rho, u = sv.moments()
         assert bits_equal(rho, rho_o) and bits_equal(u, u_o)
     sv.close()
+
+
+def test_native_ring_self_exchange(lib, oracle):
+    """The C++ slab ring (csrc/capi_ring.hip: dlopen'd RCCL, packed halo, edge stream): one rank,
+    periodic, so both neighbours are the rank itself and every launch-step does a real
+    ncclSend/ncclRecv pair per side.  Depth 5 (sliding window) and depth 1 (single-step kernel),
+    bitwise against the single-block oracle."""
+    d = dev()
+    R, C = 96, 256
+    f0 = random_state(oracle, R, C, seed=77)
+    prm = pylbm.BgkParams(1.3, 0)
+    ident = (ct.c_ubyte * 128)()
+    lib.ring_unique_id(ident)
+    for depth, launches in ((5, 3), (1, 6), (3, 2)):
+        g = pylbm.Geom(R, C, depth)
+        plane = (R + 2 * depth) * C
+        lat = [torch.zeros(9 * plane, dtype=torch.float64, device=d) for _ in range(2)]
+        ring = ct.c_void_p()
+        if depth != 5:
+            lib.ring_unique_id(ident)
+        lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
+        try:
+            f0d = upload_soa(lib, f0)           # [9][R][C] without ghosts
+            flat = pylbm.Geom(R, C, 0)
+            tmp = torch.empty_like(f0d)
+            lib.bgk_collide(_ptr(tmp), _ptr(f0d), ct.byref(flat), None, ct.byref(prm), None, None, None)
+            lat[0].view(9, R + 2 * depth, C)[:, depth:depth + R].copy_(tmp.view(9, R, C))
+            torch.cuda.synchronize()
+            lib.ring_exchange(ring, _ptr(lat[0]), None)
+            lib.ring_join(ring, None)
+            cur = 0
+            for _ in range(launches):
+                lib.ring_bgk_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), None, ct.byref(prm),
+                                  depth, 16, None)
+                cur ^= 1
+            torch.cuda.synchronize()
+            p = lat[cur].view(9, R + 2 * depth, C)[:, depth:depth + R].contiguous()
+            out = torch.empty_like(p)
+            lib.stream(_ptr(out), _ptr(p), ct.byref(flat), None, None)
+            got = download_aos(lib, out)
+            want, _, _ = oracle.bgk_periodic_steps(f0, 1.3, 1 + depth * launches)
+            assert bits_equal(got, want), (depth, ulp_diff(got, want))
+        finally:
+            lib.ring_destroy(ring)

@@ -132,3 +132,20 @@ def test_static_droplet_driver_vs_oracle(tmp_path, oracle):
                              ("phase", "psi", (96, 96))):
         got = np.fromfile(tmp_path / f"sd-{name}.f64").reshape(shape)
         assert relerr(got, want[key]) < 1e-12, name
+
+
+def test_slab_ring_box_driver_self_ring(tmp_path):
+    """C++ host of the multi-GPU path (drivers/slab_ring_box.cpp on lbm_ring_*): one forked rank whose
+    ring neighbours are itself, so every launch-step runs the packed ncclSend/ncclRecv exchange on the
+    edge stream; --check compares with the same box advanced as one ghost-free block, bit for bit."""
+    import json
+    exe = os.path.join(BIN, "slab_ring_box")
+    assert os.path.exists(exe)
+    for depth, edge in ((5, 16), (1, 8)):
+        r = subprocess.run([exe, "--spawn", "1", "--rows", "160", "--cols", "256", "--steps", "3",
+                            "--warmup", "1", "--depth", str(depth), "--edge-rows", str(edge), "--check", "1",
+                            "--id-file", str(tmp_path / f"id{depth}")],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["check"] == "bitwise equal to one block" and line["depth"] == depth
