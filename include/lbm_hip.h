@@ -243,6 +243,18 @@ int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const d
                           const double* rho_r, const double* rho_b, const double* u,
                           const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm,
                           int row_begin, int row_end, double* psi, double* s_nu, lbm_stream_t s);
+/* The whole step :431-477 in ONE launch (what lbm_cg_solver_step runs; tuning "cg_fused" = 0 selects
+ * the two passes above).  Same mathematics, reassociated: the MRT operator is applied once to the
+ * colour-summed non-equilibrium part (only the sum enters recolouring, :455), divisions by rho and
+ * |grad psi| become reciprocals, rho_k / u / psi are rebuilt inside the tile from the streamed
+ * populations (no macroscopic arrays are read; 288 B per node update instead of 496).  Results agree
+ * with the two-pass form to rounding (see tests/test_gpu_cg.py for the stated tolerance), not bit for
+ * bit.  Slabs: populations with 3 ghost rows, exactly as for the two passes.  The five field outputs
+ * (rho_r, rho_b, u with the macro layout above; psi, s_nu dense [R][C]) are optional: all or none. */
+int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                      const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int row_begin,
+                      int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* s_nu,
+                      lbm_stream_t s);
 /* driver loop context (single block); host arrays in the reference's shapes */
 typedef struct lbm_cg_solver lbm_cg_solver;
 int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* bc /* NULL = default */,

@@ -2,6 +2,7 @@
 #include <new>
 
 #include "cg.hpp"
+#include "cg_fused.hpp"
 #include "launch.hpp"
 
 namespace lbm {
@@ -71,6 +72,18 @@ static int launch_cg_collide(bool from_post, double* pn_r, double* pn_b, const d
     if (fields) LBM_KLAUNCH((k_cg_collide<false, true>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu, mi, row_begin, row_end);
     else LBM_KLAUNCH((k_cg_collide<false, false>), dim3(tiles), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, rho_r, rho_b, u, g, bc, cc, psi, snu, mi, row_begin, row_end);
   }
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+template <int TR, int TC, int WAVES>
+static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, const double* in_b,
+                             const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
+                             double* rho_b, double* u, double* psi, double* snu, const MacroIdx& mi,
+                             int row_begin, int row_end, hipStream_t st) {
+  const int tiles = ((row_end - row_begin + TR - 1) / TR) * ((g.C + TC - 1) / TC);
+  if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end);
+  else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
@@ -146,6 +159,32 @@ int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const d
   LBM_REQUIRE(pn_r != p_r && pn_b != p_b, "lbm_cg_stream_collide: aliased lattices");
   LBM_REQUIRE((psi == nullptr) == (snu == nullptr), "lbm_cg_stream_collide: psi and s_nu go together");
   return launch_cg_collide(true, pn_r, pn_b, p_r, p_b, rho_r, rho_b, u, g, bc, prm, psi, snu, row_begin, row_end, as_stream(s));
+}
+
+int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                      const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int row_begin,
+                      int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* snu,
+                      lbm_stream_t s) {
+  int rc = check_cg("lbm_cg_step_fused", g, bc, prm);
+  if (rc) return rc;
+  LBM_REQUIRE(pn_r && pn_b && p_r && p_b, "lbm_cg_step_fused: NULL lattice");
+  LBM_REQUIRE(pn_r != p_r && pn_b != p_b, "lbm_cg_step_fused: aliased lattices");
+  const bool any = rho_r || rho_b || u || psi || snu, all = rho_r && rho_b && u && psi && snu;
+  LBM_REQUIRE(any == all, "lbm_cg_step_fused: the five field outputs go together (all or none)");
+  const Geom gg = make_geom(*g);
+  const Bc bb = make_bc(bc);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= gg.R, "lbm_cg_step_fused: row range [%d, %d) outside [0, %d)", row_begin, row_end, gg.R);
+  if (row_begin == row_end) return LBM_OK;
+  const CgFast cf = make_cg_fast(make_cg_consts(*prm));
+  const MacroIdx mi = make_macro_idx(gg);
+  hipStream_t st = as_stream(s);
+  switch (tuning("cg_tile", 1)) {
+    case 0: return launch_cg_fused_t<8, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 2: return launch_cg_fused_t<8, 64, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 3: return launch_cg_fused_t<16, 32, 3>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 4: return launch_cg_fused_t<16, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    default: return launch_cg_fused_t<16, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+  }
 }
 
 }  // extern "C"
@@ -242,6 +281,13 @@ int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps) {
     if (!sv->post) {  // iteration on the given (rho, u): the driver's first pass through :431-464
       rc = lbm_cg_collide(dst[0], dst[1], src[0], src[1], sv->rho_r, sv->rho_b, sv->u, &sv->g,
                           &sv->bc, &sv->prm, sv->psi, sv->snu, sv->st);
+    } else if (tuning("cg_fused", 1)) {
+      // one launch per step; the observable fields are written by the last step of the call
+      const bool last = (i == n_steps - 1);
+      rc = lbm_cg_step_fused(dst[0], dst[1], src[0], src[1], &sv->g, &sv->bc, &sv->prm, 0, sv->g.R,
+                             last ? sv->rho_r : nullptr, last ? sv->rho_b : nullptr,
+                             last ? sv->u : nullptr, last ? sv->psi : nullptr,
+                             last ? sv->snu : nullptr, sv->st);
     } else {
       rc = lbm_cg_stream_moments(sv->rho_r, sv->rho_b, sv->u, src[0], src[1], &sv->g, &sv->bc,
                                  &sv->prm, sv->st);

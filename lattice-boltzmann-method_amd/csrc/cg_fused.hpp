@@ -1,0 +1,303 @@
+// Colour-gradient MRT two-phase step, ONE kernel per time step ("fused" path; cg.hpp keeps the
+// two-pass kernels that follow the reference operation by operation and are bit-identical to the
+// oracle).  Same mathematics (test/mrtcg_rayleigh_taylor.cpp:431-477), reassociated:
+//
+//  * only the SUM over the two colours of the relaxed populations enters recolouring (:455), and
+//    the MRT operator is linear, so ONE moment transform of d = (feq_r + feq_b) - (f_r + f_b)
+//    replaces the two 9x9 x 2 products per colour; rows 0, 3, 5 of S are zero and are skipped;
+//    the remaining 6 moments come from a butterfly over opposite pairs;
+//  * the correction terms C_k (update_C :320-336) enter only summed, so the stencil runs on
+//    Q_r + Q_b: 3 staged fields (psi, Qx, Qy) instead of 5, antisymmetric taps paired;
+//  * 36 of the 39 f64 divisions per node become multiplications by 1/rho and 1/(1e-20 + |grad psi|);
+//  * rho_r, rho_b, u are recomputed in the tile (+-2 halo ring) from the streamed populations
+//    instead of round-tripping through HBM: 288 B/LUP (read 18 + write 18 doubles) instead of
+//    the 496 B/LUP of the two-pass form; halo re-reads hit L2.
+//
+// Results differ from the reference order by rounding only (tolerance stated in
+// tests/test_gpu_cg.py); FMA contraction is enabled here, unlike the rest of the library.
+#pragma once
+#include "cg.hpp"
+
+namespace lbm {
+
+struct CgFast {
+  double inv_rho0[2], qc[2], beta[2];
+  double phi0[2], phi1[2], phi5[2];  // phi by |c|^2 class (colour.cpp:49-64)
+  double eta1[2], eta5[2];
+  double sigma, Gr, Gc;
+  int add_source;
+  double delta, r_omega, b_omega, s1, s2, s3, t2, t3;
+};
+
+inline CgFast make_cg_fast(const CgConsts& c) {
+  CgFast f;
+  for (int k = 0; k < 2; ++k) {
+    f.inv_rho0[k] = 1.0 / c.k[k].rho_0;
+    f.qc[k] = c.k[k].qcoef;
+    f.beta[k] = c.k[k].beta;
+    f.phi0[k] = c.k[k].phi[0];
+    f.phi1[k] = c.k[k].phi[1];
+    f.phi5[k] = c.k[k].phi[5];
+    f.eta1[k] = c.k[k].eta[1];
+    f.eta5[k] = c.k[k].eta[5];
+  }
+  f.sigma = c.sigma;
+  f.Gr = c.gr;
+  f.Gc = c.gc;
+  f.add_source = c.add_source;
+  f.delta = c.delta;
+  f.r_omega = c.r_omega;
+  f.b_omega = c.b_omega;
+  f.s1 = c.s1;
+  f.s2 = c.s2;
+  f.s3 = c.s3;
+  f.t2 = c.t2;
+  f.t3 = c.t3;
+  return f;
+}
+
+__device__ __forceinline__ double cg_snu_fast(const CgFast& c, double psi) {  // :84-100
+  double v = 0.0;
+  if (psi > c.delta) v = c.r_omega;
+  if (c.delta >= psi && psi > 0.0) v = c.s1 + c.s2 * psi + c.s3 * psi * psi;
+  if (0.0 >= psi && psi >= -c.delta) v = c.s1 + c.t2 * psi + c.t3 * psi * psi;
+  if (psi < -c.delta) v = c.b_omega;
+  return v;
+}
+
+// streamed populations of node (gr, gc) -> colour-summed populations and macroscopic fields
+// (:466-477), phase field (:212-225) and Q = sum_k (1.8 alpha_k - 0.8) rho_k u (:326-327)
+struct CgNode {
+  double rr, rb, ux, uy, irt, psi, qx, qy;
+};
+// INTERIOR: the node and its 8 neighbours are inside the block and no boundary fix-up applies
+template <bool INTERIOR>
+__device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restrict__ in_r,
+                                          const double* __restrict__ in_b, const Geom& g,
+                                          const Bc& bc, const CgFast& cf, int gr, int gc) {
+#pragma clang fp contract(fast)
+  double fr[Q];
+  if (INTERIOR) {
+    const long o = g.at(gr, gc);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      fr[q] = in_r[q * g.plane + (o - icx(q) * g.C - icy(q))];
+      ft[q] = in_b[q * g.plane + (o - icx(q) * g.C - icy(q))];
+    }
+  } else {
+    gather_bc(fr, in_r, g, bc, gr, gc);
+    gather_bc(ft, in_b, g, bc, gr, gc);
+  }
+  CgNode n;
+  n.rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
+  n.rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) ft[q] += fr[q];
+  const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
+  const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
+  n.irt = 1.0 / (n.rr + n.rb);
+  n.ux = (jx + 0.5 * cf.Gr) * n.irt;  // u + Fg / (2 rho), :477
+  n.uy = (jy + 0.5 * cf.Gc) * n.irt;
+  const double a = n.rr * cf.inv_rho0[0], b = n.rb * cf.inv_rho0[1];
+  n.psi = (a - b) / (a + b);
+  const double qcs = cf.qc[0] * n.rr + cf.qc[1] * n.rb;
+  n.qx = qcs * n.ux;
+  n.qy = qcs * n.uy;
+  return n;
+}
+
+// 5x5 isotropic derivative (differential.hpp:9-16) with the antisymmetric taps paired.
+// d/d(row): sum_j [ 2 a0_j (P[4][j] - P[0][j]) + a1_j (P[3][j] - P[1][j]) ]; d/d(col) transposed.
+template <int LDC>
+__device__ __forceinline__ double cg_ddrow(const double (*s)[LDC], int tr, int tc) {
+#pragma clang fp contract(fast)
+  constexpr double k = 1.0 / 5040.0;
+  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
+  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
+  double acc = 0.0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    acc += a0[j] * (s[tr + 4][tc + j] - s[tr][tc + j]);
+    acc += a1[j] * (s[tr + 3][tc + j] - s[tr + 1][tc + j]);
+  }
+  return acc;
+}
+template <int LDC>
+__device__ __forceinline__ double cg_ddcol(const double (*s)[LDC], int tr, int tc) {
+#pragma clang fp contract(fast)
+  constexpr double k = 1.0 / 5040.0;
+  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
+  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
+  double acc = 0.0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    acc += a0[i] * (s[tr + i][tc + 4] - s[tr + i][tc]);
+    acc += a1[i] * (s[tr + i][tc + 3] - s[tr + i][tc + 1]);
+  }
+  return acc;
+}
+
+template <int TR, int TC, int WAVES, bool WITH_FIELDS>
+__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end) {
+#pragma clang fp contract(fast)
+  constexpr int NT = TR * TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
+  __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
+  const int tiles_c = (g.C + TC - 1) / TC;
+  const int r_base = row_begin + (blockIdx.x / tiles_c) * TR, c_base = (blockIdx.x % tiles_c) * TC;
+  const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
+  const int tr = threadIdx.x / TC, tc = threadIdx.x % TC;
+  const int r = r_base + tr, c = c_base + tc;
+
+  // own node first (keeps the colour-summed populations in registers), then the +-2 ring.
+  // Replicate padding of the stencils = clamping the node the fields are evaluated at
+  // (differential.cpp:5-9) -- at the edges of the GLOBAL domain only; across a slab seam the
+  // ring continues into the neighbour's (ghost) rows.
+  double ft[Q];
+  CgNode me;
+  constexpr int NH = LR * LC - TR * TC;
+  auto ring_slot = [&](int i, int& lr, int& lc) {
+    if (i < 2 * LC) {
+      lr = i / LC;
+      lc = i % LC;
+    } else if (i < 4 * LC) {
+      lr = TR + 2 + (i - 2 * LC) / LC;
+      lc = (i - 2 * LC) % LC;
+    } else {
+      const int j = i - 4 * LC;
+      lr = 2 + (j >> 2);
+      lc = (j & 3) < 2 ? (j & 3) : TC + (j & 3);
+    }
+  };
+  {
+    me = cg_node<false>(ft, in_r, in_b, g, bc, cf, r > rhi ? rhi : r, c > g.C - 1 ? g.C - 1 : c);
+    for (int i = threadIdx.x; i < NH; i += NT) {
+      int lr, lc;
+      ring_slot(i, lr, lc);
+      int gr = r_base + lr - 2, gc = c_base + lc - 2;
+      gr = gr < rlo ? rlo : (gr > rhi ? rhi : gr);
+      gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
+      double tmp[Q];
+      const CgNode nb = cg_node<false>(tmp, in_r, in_b, g, bc, cf, gr, gc);
+      s_psi[lr][lc] = nb.psi;
+      s_qx[lr][lc] = nb.qx;
+      s_qy[lr][lc] = nb.qy;
+    }
+  }
+  s_psi[tr + 2][tc + 2] = me.psi;
+  s_qx[tr + 2][tc + 2] = me.qx;
+  s_qy[tr + 2][tc + 2] = me.qy;
+  __syncthreads();
+  if (r >= row_end || c >= g.C) return;
+
+  const double gx = cg_ddrow<LDC>(s_psi, tr, tc), gy = cg_ddcol<LDC>(s_psi, tr, tc);
+  const double dxqx = cg_ddrow<LDC>(s_qx, tr, tc), dyqy = cg_ddcol<LDC>(s_qy, tr, tc);
+
+  const double rr = me.rr, rb = me.rb, ux = me.ux, uy = me.uy, irt = me.irt;
+  const double rt = rr + rb;
+  const double s_nu = cg_snu_fast(cf, me.psi);
+  constexpr double W0 = 4.0 / 9.0, W1 = 1.0 / 9.0, W5 = 1.0 / 36.0;
+  constexpr double B0 = -4.0 / 27.0, B1 = 2.0 / 27.0, B5 = 5.0 / 108.0;  // :158-163
+
+  // perturbation operator (:263-273, :290-300), identical for both colours: 5 distinct values
+  const double gn = sqrt(gx * gx + gy * gy);
+  const double ig = 1.0 / (1e-20 + gn);
+  const double hA = 0.5 * (4.5 * cf.sigma * s_nu) * gn;
+  const double ig2 = ig * ig, gs = gx + gy, gd = gx - gy;
+  const double p0 = -2.0 * hA * B0;  // 2 Omega2 (once per colour)
+  const double p1 = 2.0 * hA * (W1 * (gx * gx * ig2) - B1), p2 = 2.0 * hA * (W1 * (gy * gy * ig2) - B1);
+  const double p5 = 2.0 * hA * (W5 * (gs * gs * ig2) - B5), p6 = 2.0 * hA * (W5 * (gd * gd * ig2) - B5);
+
+  // feq_r + feq_b (:233-247) split into the parts even and odd under c -> -c
+  const double P0 = rr * cf.phi0[0] + rb * cf.phi0[1], P1 = rr * cf.phi1[0] + rb * cf.phi1[1],
+               P5 = rr * cf.phi5[0] + rb * cf.phi5[1];
+  const double H1 = rr * cf.eta1[0] + rb * cf.eta1[1], H5 = rr * cf.eta5[0] + rb * cf.eta5[1];
+  const double c3 = -3.0 * (ux * ux + uy * uy), us = ux + uy, ud = ux - uy;
+  const double E0 = P0 + W0 * rt * c3;
+  const double E1 = P1 + W1 * rt * (9.0 * ux * ux + c3), E2 = P1 + W1 * rt * (9.0 * uy * uy + c3);
+  const double E5 = P5 + W5 * rt * (9.0 * us * us + c3), E6 = P5 + W5 * rt * (9.0 * ud * ud + c3);
+  const double O1 = (3.0 * W1) * H1 * ux, O2 = (3.0 * W1) * H1 * uy;
+  const double O5 = (3.0 * W5) * H5 * us, O8 = (3.0 * W5) * H5 * ud;
+  const double d0 = E0 - ft[0];
+  const double d1 = (E1 + O1) - ft[1], d3 = (E1 - O1) - ft[3];
+  const double d2 = (E2 + O2) - ft[2], d4 = (E2 - O2) - ft[4];
+  const double d5 = (E5 + O5) - ft[5], d7 = (E5 - O5) - ft[7];
+  const double d8 = (E6 + O8) - ft[8], d6 = (E6 - O8) - ft[6];
+
+  // M d for the 6 relaxed moments (:130-140, rows 1, 2, 4, 6, 7, 8)
+  const double a = d1 + d3, b = d2 + d4, p = d5 + d7, qd = d6 + d8, cd = p + qd, ab = a + b;
+  const double e13 = d1 - d3, e24 = d2 - d4, e57 = d5 - d7, e68 = d6 - d8;
+  const double m1 = 2.0 * cd - 4.0 * d0 - ab;
+  const double m2 = 4.0 * d0 - 2.0 * ab + cd;
+  const double m4 = (e57 - e68) - 2.0 * e13;
+  const double m6 = (e57 + e68) - 2.0 * e24;
+  const double m7 = a - b, m8 = p - qd;
+  // S m + C_r + C_b (:249-261, :320-336)
+  const double n1 = 1.25 * m1 + 1.125 * (dxqx + dyqy);
+  const double n2 = 1.14 * m2;
+  const double n4 = 1.6 * m4, n6 = 1.6 * m6;
+  const double n7 = s_nu * m7 + (1.0 - 0.5 * s_nu) * (dxqx - dyqy);
+  const double n8 = s_nu * m8;
+  // M^-1 (:146-156)
+  const double A = (-1.0 / 36.0) * (n1 + 2.0 * n2), Bq = (1.0 / 36.0) * (2.0 * n1 + n2);
+  const double k4 = (1.0 / 6.0) * n4, k6 = (1.0 / 6.0) * n6, k7 = 0.25 * n7, k8 = 0.25 * n8;
+  const double h4 = 0.5 * k4, h6 = 0.5 * k6;
+  double tot[Q];  // total_f, :455
+  tot[0] = ft[0] + (1.0 / 9.0) * (n2 - n1) + p0;
+  tot[1] = ft[1] + ((A - k4) + k7) + p1;
+  tot[3] = ft[3] + ((A + k4) + k7) + p1;
+  tot[2] = ft[2] + ((A - k6) - k7) + p2;
+  tot[4] = ft[4] + ((A + k6) - k7) + p2;
+  tot[5] = ft[5] + ((Bq + h4) + (h6 + k8)) + p5;
+  tot[6] = ft[6] + ((Bq - h4) + (h6 - k8)) + p6;
+  tot[7] = ft[7] + ((Bq - h4) - (h6 - k8)) + p5;
+  tot[8] = ft[8] + ((Bq + h4) - (h6 + k8)) + p6;
+
+  // recolouring (:275-288, :302-318): kappa_q = rho_r rho_b (grad psi . c_q/|c_q|) P_q / (rho^2 |grad psi|)
+  const double xr = rr * irt, xb = rb * irt;
+  const double kk = (rr * rb) * (ig * (irt * irt));
+  const double K1 = kk * P1, K5 = (kk * P5) * 0.70710678118654752440;
+  double kap[Q];
+  kap[0] = 0.0;
+  kap[1] = K1 * gx;
+  kap[3] = -kap[1];
+  kap[2] = K1 * gy;
+  kap[4] = -kap[2];
+  kap[5] = K5 * gs;
+  kap[7] = -kap[5];
+  kap[8] = K5 * gd;
+  kap[6] = -kap[8];
+  double src[Q];
+  if (cf.add_source) {  // :460-464 (unweighted Guo-type term)
+    const double sf = 1.0 - 0.5 * s_nu, uFg3 = 3.0 * (ux * cf.Gr + uy * cf.Gc);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+      const double FgE = cf.Gr * (double)icx(q) + cf.Gc * (double)icy(q);
+      src[q] = (sf * wq(q)) * ((3.0 + 9.0 * cu) * FgE - uFg3);
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) src[q] = 0.0;
+  }
+  const long lo = g.at(r, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    pn_r[q * g.plane + lo] = (xr * tot[q] + cf.beta[0] * kap[q]) + src[q];
+    pn_b[q * g.plane + lo] = (xb * tot[q] + cf.beta[1] * kap[q]) + src[q];
+  }
+  if (WITH_FIELDS) {
+    const long o = mi.at(r, c), oo = (long)r * g.C + c;  // diagnostics carry no ghost rows
+    rho_r_out[o] = rr;
+    rho_b_out[o] = rb;
+    u_out[o] = ux;
+    u_out[mi.n + o] = uy;
+    psi_out[oo] = me.psi;
+    snu_out[oo] = s_nu;
+  }
+}
+
+}  // namespace lbm

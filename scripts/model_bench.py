@@ -81,8 +81,17 @@ def bench_cg(R, C, n=20):
     sv = pylbm.CgSolver(lib, R, C, prm)
     sv.set_state(np.moveaxis(f_r.cpu().numpy(), 0, -1), np.moveaxis(f_b.cpu().numpy(), 0, -1), rho_r, rho_b, u)
     del f_r, f_b
+    tiles = os.environ.get("LBM_CG_TILES", "1").split(",")
+    for tile in tiles:
+        lib.set_tuning(b"cg_fused", 1)
+        lib.set_tuning(b"cg_tile", int(tile))
+        dt = timed(lambda k: sv.step(k), n, warm=3)
+        report("colour-gradient MRT (fused, one launch per step, tile %s)" % tile, R, C, dt, 288)
+    lib.set_tuning(b"cg_fused", 0)
     dt = timed(lambda k: sv.step(k), n, warm=3)
-    report("colour-gradient MRT (two-pass)", R, C, dt, 496)
+    report("colour-gradient MRT (two-pass, reference operation order)", R, C, dt, 496)
+    lib.set_tuning(b"cg_fused", -1)
+    lib.set_tuning(b"cg_tile", -1)
     sv.close()
 
 
