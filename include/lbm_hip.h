@@ -117,11 +117,14 @@ typedef struct lbm_bc {
 } lbm_bc;
 
 /* ---- slab halo (multi-GPU): pack the rows a neighbour needs into ONE contiguous message -------
- * depth = ghost rows in use (1: one step per launch, n: n-step launches, 3: colour gradient).
- * Message = lbm_halo_rows(depth) rows of C doubles: 3 for depth 1, else 9 (depth - 1)
+ * depth = ghost rows in use (1: one step per launch, n: n-step launches), or LBM_HALO_TWO_PHASE for
+ * the colour-gradient step (3 ghost rows; the second row travels complete because of the driver's
+ * same-row column copy, mrtcg_rayleigh_taylor.cpp:517-523).
+ * Message = lbm_halo_rows(depth) rows of C doubles: 3 for depth 1, else 9 (depth - 1); 21 two-phase
  * (the block binding of test/decompose_domain.cpp:181-187 generalised).
  * pack  side 1: my last `depth` rows  -> message for the NEXT slab;  side 0: my first rows -> PREVIOUS.
  * unpack side 0: message from the PREVIOUS slab -> ghost rows above row 0;  side 1: from NEXT -> below. */
+#define LBM_HALO_TWO_PHASE (-3)
 int lbm_halo_rows(int depth);
 int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
                   lbm_stream_t s);
@@ -342,12 +345,21 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
 int lbm_ring_destroy(lbm_ring* rg);
 /* refresh the ghost rows of `lattice` (ordered after the work enqueued on `after`); asynchronous */
 int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after);
+/* same for two lattices in one message per neighbour (both colours of the two-phase model) */
+int lbm_ring_exchange2(lbm_ring* rg, double* lattice_a, double* lattice_b, lbm_stream_t after);
 /* make `main` wait for the ring's stream */
 int lbm_ring_join(lbm_ring* rg, lbm_stream_t main);
 /* one overlapped launch-step of a BGK slab: n_steps = 1 (single-step kernel) or 2..ghost (sliding
  * window); bc: the physical edges of the GLOBAL domain (NULL = periodic), seams become HALO */
 int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
                       const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
+
+/* one overlapped step of a two-phase (colour-gradient) slab: lbm_cg_step_fused on edge and interior
+ * rows + ONE exchange of the 3 ghost rows of both colours (slab ghost must be 3; bc NULL = the
+ * driver's walls, seams become HALO) */
+int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* src_r,
+                     const double* src_b, const lbm_bc* bc, const lbm_cg_params* prm, int edge_rows,
+                     lbm_stream_t main);
 
 /* ---- snapshots and checkpoints (the reference only torch::save()s snapshot
  * stacks at the end of a run, e.g. horizontal_poiseuille_test.cpp:157-160) ------------------------ */

@@ -129,8 +129,14 @@ __global__ __launch_bounds__(256) void k_halo_copy(double* __restrict__ dst,
 // rows of the depth-D halo in message order.  side 1: towards the NEXT slab (c_x = +1 leave);
 // side 0: towards the PREVIOUS one.  sender = true: the owned rows to send; false: the ghost rows
 // to fill on the receiving side (the receiver's `side` is where the message comes FROM).
-static int halo_table(HaloTable& t, int depth, int side, bool sender, int R) {
+static int halo_table(HaloTable& t, int depth_code, int side, bool sender, int R) {
   static const short out_next[3] = {1, 5, 8}, out_prev[3] = {3, 6, 7}, rest[3] = {0, 2, 4};
+  // two-phase step (LBM_HALO_TWO_PHASE): 3 ghost rows like a 3-step launch, but the driver's
+  // same-row column copy (mrtcg_rayleigh_taylor.cpp:517-523) makes the nodes of ghost
+  // row 2 at columns 0 / C-1 read populations {2,5,6} / {4,7,8} of their OWN row, so the second
+  // row travels complete as well: 9 + 9 + 3 rows.
+  const bool two_phase = depth_code == LBM_HALO_TWO_PHASE;
+  const int depth = two_phase ? 3 : depth_code;
   t.n = 0;
   for (int k = 0; k < depth; ++k) {
     short pops[9];
@@ -139,7 +145,7 @@ static int halo_table(HaloTable& t, int depth, int side, bool sender, int R) {
     // c_x = 0 and outward (k = D-2), outward only (k = D-1)   [pylbm/slab.py _halo_table]
     const bool towards_next = sender ? (side == 1) : (side == 0);
     const short* outward = towards_next ? out_next : out_prev;
-    if (k <= depth - 3) {
+    if (k <= depth - 3 || (two_phase && k == 1)) {
       for (short q = 0; q < 9; ++q) pops[np++] = q;
     } else if (k == depth - 2) {
       for (int j = 0; j < 3; ++j) pops[np++] = rest[j];
@@ -166,12 +172,15 @@ using namespace lbm;
 
 extern "C" {
 
-int lbm_halo_rows(int depth) { return depth <= 1 ? 3 : 9 * (depth - 1); }
+int lbm_halo_rows(int depth) { return depth == LBM_HALO_TWO_PHASE ? 21 : (depth <= 1 ? 3 : 9 * (depth - 1)); }
 
 int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
                   lbm_stream_t s) {
-  LBM_REQUIRE(buf && lattice && g && depth >= 1 && depth <= 8 && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
-  LBM_REQUIRE(g->ghost >= depth && g->R >= depth && g->R < 32000, "lbm_halo_pack: ghost=%d R=%d vs depth %d", g->ghost, g->R, depth);
+  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE) && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
+  {
+    const int need = depth == LBM_HALO_TWO_PHASE ? 3 : depth;
+    LBM_REQUIRE(g->ghost >= need && g->R >= need && g->R < 32000, "lbm_halo_pack: ghost=%d R=%d vs depth %d", g->ghost, g->R, need);
+  }
   HaloTable t;
   LBM_REQUIRE(halo_table(t, depth, side, true, g->R) > 0, "lbm_halo_pack: depth too large");
   const Geom gg = make_geom(*g);
@@ -183,8 +192,11 @@ int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int dep
 
 int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int depth, int side,
                     lbm_stream_t s) {
-  LBM_REQUIRE(buf && lattice && g && depth >= 1 && depth <= 8 && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
-  LBM_REQUIRE(g->ghost >= depth && g->R >= depth && g->R < 32000, "lbm_halo_unpack: ghost=%d R=%d vs depth %d", g->ghost, g->R, depth);
+  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE) && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
+  {
+    const int need = depth == LBM_HALO_TWO_PHASE ? 3 : depth;
+    LBM_REQUIRE(g->ghost >= need && g->R >= need && g->R < 32000, "lbm_halo_unpack: ghost=%d R=%d vs depth %d", g->ghost, g->R, need);
+  }
   HaloTable t;
   LBM_REQUIRE(halo_table(t, depth, side, false, g->R) > 0, "lbm_halo_unpack: depth too large");
   const Geom gg = make_geom(*g);

@@ -130,8 +130,10 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&rg->edge, hipStreamNonBlocking, hi);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->main_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->edge_done, hipEventDisableTiming);
+  // room for the two-colour message of the two-phase step when the slab has its 3 ghost rows
+  const size_t bufsz = slab->ghost == 3 ? 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C : rg->msg;
   for (double** p : {&rg->send_next, &rg->send_prev, &rg->recv_prev, &rg->recv_next})
-    if (e == hipSuccess) e = hipMalloc(p, rg->msg * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(p, bufsz * sizeof(double));
   if (e != hipSuccess) {
     set_error("lbm_ring_create: %s", hipGetErrorString(e));
     lbm_ring_destroy(rg);
@@ -154,40 +156,99 @@ int lbm_ring_destroy(lbm_ring* rg) {
   return LBM_OK;
 }
 
-// Bring the ghost rows of `lattice` up to date: pack, one send + one recv per neighbour in one
-// RCCL group, unpack -- all enqueued on the ring's edge stream, after the work already enqueued
-// on `after`.
-int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after) {
-  LBM_REQUIRE(rg && lattice, "lbm_ring_exchange: NULL argument");
-  const int G = rg->g.ghost;
+// Bring the ghost rows of `lattice` (and of `lattice2`, if given: the second colour of the
+// two-phase model travels in the same message) up to date: pack, one send + one recv per neighbour
+// in one RCCL group, unpack -- all enqueued on the ring's edge stream, after the work already
+// enqueued on `after`.
+static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_stream_t after) {
+  const int G = lattice2 ? LBM_HALO_TWO_PHASE : rg->g.ghost;  // two lattices = the two colours
+  const size_t msg = (size_t)lbm_halo_rows(G) * rg->g.C;
   if (as_stream(after) != rg->edge) {
     LBM_CHECK_HIP(hipEventRecord(rg->main_done, as_stream(after)));
     LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
   }
-  if (rg->next >= 0) {
-    int rc = lbm_halo_pack(rg->send_next, lattice, &rg->g, G, 1, rg->edge);
-    if (rc) return rc;
-  }
-  if (rg->prev >= 0) {
-    int rc = lbm_halo_pack(rg->send_prev, lattice, &rg->g, G, 0, rg->edge);
-    if (rc) return rc;
+  double* lats[2] = {lattice, lattice2};
+  const int nl = lattice2 ? 2 : 1;
+  const size_t count = msg * nl;
+  for (int k = 0; k < nl; ++k) {
+    if (rg->next >= 0) {
+      int rc = lbm_halo_pack(rg->send_next + k * msg, lats[k], &rg->g, G, 1, rg->edge);
+      if (rc) return rc;
+    }
+    if (rg->prev >= 0) {
+      int rc = lbm_halo_pack(rg->send_prev + k * msg, lats[k], &rg->g, G, 0, rg->edge);
+      if (rc) return rc;
+    }
   }
   LBM_CHECK_NCCL(g_rccl.GroupStart());
   // sends (to next, to prev), receives (from prev, from next): with two ranks both neighbours
   // are the same peer and messages match in issue order
-  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_next, rg->msg, kNcclFloat64, rg->next, rg->comm, rg->edge));
-  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_prev, rg->msg, kNcclFloat64, rg->prev, rg->comm, rg->edge));
-  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_prev, rg->msg, kNcclFloat64, rg->prev, rg->comm, rg->edge));
-  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_next, rg->msg, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_next, count, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_prev, count, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_prev, count, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_next, count, kNcclFloat64, rg->next, rg->comm, rg->edge));
   LBM_CHECK_NCCL(g_rccl.GroupEnd());
-  if (rg->prev >= 0) {
-    int rc = lbm_halo_unpack(lattice, rg->recv_prev, &rg->g, G, 0, rg->edge);
-    if (rc) return rc;
+  for (int k = 0; k < nl; ++k) {
+    if (rg->prev >= 0) {
+      int rc = lbm_halo_unpack(lats[k], rg->recv_prev + k * msg, &rg->g, G, 0, rg->edge);
+      if (rc) return rc;
+    }
+    if (rg->next >= 0) {
+      int rc = lbm_halo_unpack(lats[k], rg->recv_next + k * msg, &rg->g, G, 1, rg->edge);
+      if (rc) return rc;
+    }
   }
-  if (rg->next >= 0) {
-    int rc = lbm_halo_unpack(lattice, rg->recv_next, &rg->g, G, 1, rg->edge);
-    if (rc) return rc;
+  return LBM_OK;
+}
+
+int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after) {
+  LBM_REQUIRE(rg && lattice, "lbm_ring_exchange: NULL argument");
+  return ring_exchange(rg, lattice, nullptr, after);
+}
+
+int lbm_ring_exchange2(lbm_ring* rg, double* lattice_a, double* lattice_b, lbm_stream_t after) {
+  LBM_REQUIRE(rg && lattice_a && lattice_b, "lbm_ring_exchange2: NULL argument");
+  LBM_REQUIRE(rg->g.ghost == 3, "lbm_ring_exchange2: two-phase exchange needs 3 ghost rows (ring has %d)", rg->g.ghost);
+  return ring_exchange(rg, lattice_a, lattice_b, after);
+}
+
+// One overlapped step of the two-phase (colour-gradient) slab: the fused one-launch step on the
+// edge rows (edge stream) and on the interior rows (main stream, concurrently), ONE exchange of
+// the 3 ghost rows of both colours behind the edge rows.  The slab geometry must carry 3 ghost
+// rows; bc = the physical edges of the GLOBAL domain (NULL = the driver's walls,
+// lbm_cg_default_bc), seams become HALO.
+int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* src_r,
+                     const double* src_b, const lbm_bc* bc, const lbm_cg_params* prm, int edge_rows,
+                     lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && dst_r && dst_b && src_r && src_b && prm, "lbm_ring_cg_step: NULL argument");
+  const int R = rg->g.R, G = rg->g.ghost;
+  LBM_REQUIRE(G == 3, "lbm_ring_cg_step: the two-phase step needs 3 ghost rows (ring has %d)", G);
+  if (edge_rows < G) edge_rows = G;
+  LBM_REQUIRE(2 * edge_rows < R, "lbm_ring_cg_step: edge_rows=%d too large for %d rows", edge_rows, R);
+  hipStream_t main = as_stream(main_s);
+  lbm_bc b;
+  if (bc) b = *bc;
+  else lbm_cg_default_bc(&b);
+  if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
+  if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  auto rows = [&](int r0, int r1, hipStream_t st) -> int {
+    return lbm_cg_step_fused(dst_r, dst_b, src_r, src_b, &rg->g, &b, prm, r0, r1, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, st);
+  };
+  LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
+  LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+  int rc = LBM_OK;
+  if (rg->prev >= 0 || rg->next >= 0) {
+    rc = rows(0, edge_rows, rg->edge);
+    if (!rc) rc = rows(R - edge_rows, R, rg->edge);
+    if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
+    if (!rc) rc = ring_exchange(rg, dst_r, dst_b, rg->edge);
+  } else {
+    rc = rows(0, R, main);
   }
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+  LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
   return LBM_OK;
 }
 
@@ -216,7 +277,7 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   int rc = rows(0, edge_rows, rg->edge);
   if (!rc) rc = rows(R - edge_rows, R, rg->edge);
   if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
-  if (!rc) rc = lbm_ring_exchange(rg, dst, rg->edge);
+  if (!rc) rc = ring_exchange(rg, dst, nullptr, rg->edge);
   if (rc) return rc;
   LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
   LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));

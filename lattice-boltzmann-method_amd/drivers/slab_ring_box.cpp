@@ -26,36 +26,9 @@
 
 #include "../../include/lbm_hip.h"
 #include "common.hpp"
+#include "ring_common.hpp"
 
 namespace {
-
-void check(int rc, const char* what) {
-  if (rc != 0) throw std::runtime_error(std::string(what) + ": " + lbm_last_error_string());
-}
-
-bool read_file(const std::string& path, void* buf, size_t n) {
-  FILE* f = std::fopen(path.c_str(), "rb");
-  if (!f) return false;
-  size_t got = std::fread(buf, 1, n, f);
-  std::fclose(f);
-  return got == n;
-}
-void write_file_atomic(const std::string& path, const void* buf, size_t n) {
-  std::string tmp = path + ".tmp";
-  FILE* f = std::fopen(tmp.c_str(), "wb");
-  if (!f) throw std::runtime_error("cannot write " + tmp);
-  std::fwrite(buf, 1, n, f);
-  std::fclose(f);
-  std::rename(tmp.c_str(), path.c_str());
-}
-void wait_file(const std::string& path, void* buf, size_t n, double timeout_s = 120) {
-  auto t0 = std::chrono::steady_clock::now();
-  while (!read_file(path, buf, n)) {
-    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
-      throw std::runtime_error("timed out waiting for " + path);
-    std::this_thread::sleep_for(std::chrono::milliseconds(5));
-  }
-}
 
 // Taylor-Green-like smooth field on the GLOBAL box -> compressible equilibrium (solver.cpp:51-62)
 // for global row gr, column c; written in the reference's operation order so that the N-rank and
@@ -224,32 +197,9 @@ int main(int argc, char** argv) {
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
   try {
     if (spawn > 0) {
-      // fork BEFORE anything touches the GPU; every child is an ordinary one-GPU process
-      std::vector<pid_t> kids;
-      for (int r = 0; r < spawn; ++r) {
-        pid_t pid = fork();
-        if (pid == 0) {
-          int rc = 1;
-          try {
-            rc = run_rank(a, r, spawn, r);
-          } catch (const std::exception& e) {
-            std::fprintf(stderr, "rank %d: %s\n", r, e.what());
-          }
-          std::fflush(nullptr);
-          _exit(rc);
-        }
-        kids.push_back(pid);
-      }
-      int worst = 0;
-      for (pid_t k : kids) {
-        int st = 0;
-        waitpid(k, &st, 0);
-        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
-      }
-      for (const char* suf : {"", ".tmp"}) std::remove((a.id_file + suf).c_str());
-      for (int r = 0; r < spawn; ++r)
-        for (const char* suf : {".t", ".f"}) std::remove((a.id_file + suf + std::to_string(r)).c_str());
-      return worst;
+      const int rc = spawn_ranks(spawn, [&](int r) { return run_rank(a, r, spawn, r); });
+      cleanup_ring_files(a.id_file, spawn);
+      return rc;
     }
     const char* er = std::getenv("RANK");
     const char* ew = std::getenv("WORLD_SIZE");

@@ -1,0 +1,198 @@
+// Rayleigh-Taylor two-phase run (BASELINE config 4) slab-decomposed along r over the GPUs of one
+// node: a CHAIN of slabs (rows 0 and R-1 of the global domain are the driver's bounce-back walls,
+// test/mrtcg_rayleigh_taylor.cpp:525-531), 3 ghost rows per colour, ONE packed message per
+// neighbour per step (both colours), exchange overlapped with the interior rows.  C++ host on
+// lbm_ring_* + lbm_cg_step_fused; one process per GPU.
+//
+//   slab_ring_rt --spawn N [--rows R_per_gpu] [--cols C] [--steps K] [--warmup W] [--edge-rows E]
+//                [--check 1]   (rank 0 recomputes the whole domain as one block: small sizes only)
+//   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_rt --id-file /tmp/x ...     under any launcher
+//
+// Parameters: [red]/[blue] of mrtcg-rayleigh-taylor-gamma3.toml, sigma = 0.1, g = 6.25e-6
+// (SURVEY 8d, C4); initial state = init_rho_cosine (:182-210), u = 0, f = feq.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "common.hpp"
+#include "ring_common.hpp"
+
+namespace {
+
+struct Args {
+  int rows = 2048, cols = 2048, steps = 50, warmup = 5, edge_rows = 16, check = 0;
+  std::string id_file;
+};
+
+lbm_cg_params rt_params() {
+  lbm_cg_params p{};
+  p.red = lbm_cg_colour{3.0, 0.7, 0.04, 0.7};
+  p.blue = lbm_cg_colour{1.0, 0.1, 0.04, -0.7};
+  p.sigma = 0.1;
+  p.gravity_r = 6.25e-6;
+  p.gravity_c = 0.0;
+  p.add_source = 1;
+  p.delta = 0.1;
+  return p;
+}
+
+// Post-collision lattices of rows [row0, row0 + R) of an Rg x C domain, ghost rows G (0 or 3):
+// densities by init_rho_cosine, f = feq(rho_k, u = 0), then the driver's first collision
+// (lbm_cg_collide on the given rho, u).  The macroscopic arrays of a slab carry 2 ghost rows.
+void make_slab(int R, int C, int row0, int Rg, const lbm_geom& g, const lbm_bc& bc,
+               const lbm_cg_params& prm, double** post_r, double** post_b) {
+  const int G = g.ghost, mg = G ? 2 : 0;
+  const size_t plane = (size_t)(R + 2 * G) * C, mplane = (size_t)(R + 2 * mg) * C;
+  std::vector<double> hr(mplane), hb(mplane);
+  for (int r = -mg; r < R + mg; ++r) {
+    int gr = row0 + r;
+    gr = gr < 0 ? 0 : (gr > Rg - 1 ? Rg - 1 : gr);
+    for (int c = 0; c < C; ++c) {
+      const double s = Rg / 2.0 - 0.1 * C * std::cos(2.0 * 3.141592 * c / C);  // :196-199
+      const bool red = gr < s;
+      hr[(size_t)(r + mg) * C + c] = red ? prm.red.rho_0 : 0.0;
+      hb[(size_t)(r + mg) * C + c] = red ? 0.0 : prm.blue.rho_0;
+    }
+  }
+  double *d_rr, *d_rb, *d_u, *pre_r, *pre_b;
+  check(lbm_malloc((void**)&d_rr, mplane * 8), "lbm_malloc");
+  check(lbm_malloc((void**)&d_rb, mplane * 8), "lbm_malloc");
+  check(lbm_malloc((void**)&d_u, 2 * mplane * 8), "lbm_malloc");
+  check(lbm_malloc((void**)&pre_r, 9 * plane * 8), "lbm_malloc");
+  check(lbm_malloc((void**)&pre_b, 9 * plane * 8), "lbm_malloc");
+  check(lbm_malloc((void**)post_r, 9 * plane * 8), "lbm_malloc");
+  check(lbm_malloc((void**)post_b, 9 * plane * 8), "lbm_malloc");
+  check(lbm_memcpy_h2d(d_rr, hr.data(), mplane * 8, nullptr), "h2d");
+  check(lbm_memcpy_h2d(d_rb, hb.data(), mplane * 8, nullptr), "h2d");
+  check(lbm_memset(d_u, 0, 2 * mplane * 8, nullptr), "memset");
+  for (double* p : {pre_r, pre_b, *post_r, *post_b}) check(lbm_memset(p, 0, 9 * plane * 8, nullptr), "memset");
+  // feq on the owned rows, written straight into the ghosted lattices (u = 0: dense zeros)
+  check(lbm_cg_equilibrium(pre_r + (size_t)G * C, d_rr + (size_t)mg * C, d_u, &prm.red, R, C, (long long)plane, nullptr), "lbm_cg_equilibrium");
+  check(lbm_cg_equilibrium(pre_b + (size_t)G * C, d_rb + (size_t)mg * C, d_u, &prm.blue, R, C, (long long)plane, nullptr), "lbm_cg_equilibrium");
+  check(lbm_cg_collide(*post_r, *post_b, pre_r, pre_b, d_rr, d_rb, d_u, &g, &bc, &prm, nullptr, nullptr, nullptr), "lbm_cg_collide");
+  check(lbm_stream_sync(nullptr), "sync");
+  for (double* p : {d_rr, d_rb, d_u, pre_r, pre_b}) lbm_free(p);
+}
+
+int run_rank(const Args& a, int rank, int world, int local_rank) {
+  check(lbm_set_device(local_rank), "lbm_set_device");
+  const int R = a.rows, C = a.cols, Rg = R * world, G = 3;
+  const lbm_cg_params prm = rt_params();
+  lbm_geom g{R, C, G, 0};
+  lbm_bc bc;
+  lbm_cg_default_bc(&bc);
+  if (rank > 0) bc.row_lo = LBM_EDGE_HALO;
+  if (rank < world - 1) bc.row_hi = LBM_EDGE_HALO;
+
+  unsigned char id[128];
+  share_unique_id(id, rank, world, a.id_file);
+  lbm_ring* ring = nullptr;
+  check(lbm_ring_create(&ring, id, rank, world, &g, /*periodic=*/0), "lbm_ring_create");
+
+  const size_t plane = (size_t)(R + 2 * G) * C;
+  double* lat[2][2];
+  make_slab(R, C, rank * R, Rg, g, bc, prm, &lat[0][0], &lat[0][1]);
+  for (int k = 0; k < 2; ++k) {
+    check(lbm_malloc((void**)&lat[1][k], 9 * plane * 8), "lbm_malloc");
+    check(lbm_memset(lat[1][k], 0, 9 * plane * 8, nullptr), "memset");
+  }
+  check(lbm_ring_exchange2(ring, lat[0][0], lat[0][1], nullptr), "lbm_ring_exchange2");
+  check(lbm_ring_join(ring, nullptr), "lbm_ring_join");
+
+  int cur = 0;
+  auto step = [&]() {
+    check(lbm_ring_cg_step(ring, lat[cur ^ 1][0], lat[cur ^ 1][1], lat[cur][0], lat[cur][1], nullptr, &prm,
+                           a.edge_rows, nullptr), "lbm_ring_cg_step");
+    cur ^= 1;
+  };
+  for (int i = 0; i < a.warmup; ++i) step();
+  check(lbm_stream_sync(nullptr), "sync");
+  auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < a.steps; ++i) step();
+  check(lbm_stream_sync(nullptr), "sync");
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  const double tmax = max_time_over_ranks(sec, rank, world, a.id_file);
+
+  int bad = 0;
+  if (a.check) {
+    std::vector<double> h(9 * plane), own((size_t)18 * R * C);
+    for (int k = 0; k < 2; ++k) {
+      check(lbm_memcpy_d2h(h.data(), lat[cur][k], h.size() * 8, nullptr), "d2h");
+      check(lbm_stream_sync(nullptr), "sync");
+      for (int q = 0; q < 9; ++q)
+        std::memcpy(&own[((size_t)k * 9 + q) * R * C], &h[q * plane + (size_t)G * C], (size_t)R * C * 8);
+    }
+    write_file_atomic(a.id_file + ".f" + std::to_string(rank), own.data(), own.size() * 8);
+    if (rank == 0) {
+      lbm_geom gw{Rg, C, 0, 0};
+      lbm_bc bw;
+      lbm_cg_default_bc(&bw);
+      double *p[2], *q2[2];
+      make_slab(Rg, C, 0, Rg, gw, bw, prm, &p[0], &p[1]);
+      const size_t n = (size_t)9 * Rg * C;
+      for (int k = 0; k < 2; ++k) check(lbm_malloc((void**)&q2[k], n * 8), "lbm_malloc");
+      for (int t = 0; t < a.warmup + a.steps; ++t) {
+        check(lbm_cg_step_fused(q2[0], q2[1], p[0], p[1], &gw, &bw, &prm, 0, Rg, nullptr, nullptr, nullptr,
+                                nullptr, nullptr, nullptr), "lbm_cg_step_fused");
+        std::swap(p[0], q2[0]);
+        std::swap(p[1], q2[1]);
+      }
+      std::vector<double> want(n);
+      for (int k = 0; k < 2; ++k) {
+        check(lbm_memcpy_d2h(want.data(), p[k], n * 8, nullptr), "d2h");
+        check(lbm_stream_sync(nullptr), "sync");
+        for (int r = 0; r < world; ++r) {
+          wait_file(a.id_file + ".f" + std::to_string(r), own.data(), own.size() * 8);
+          for (int q = 0; q < 9; ++q)
+            if (std::memcmp(&own[((size_t)k * 9 + q) * R * C], &want[(size_t)q * Rg * C + (size_t)r * R * C],
+                            (size_t)R * C * 8) != 0)
+              ++bad;
+        }
+      }
+      for (int k = 0; k < 2; ++k) {
+        lbm_free(p[k]);
+        lbm_free(q2[k]);
+      }
+    }
+  }
+  if (rank == 0) {
+    std::printf("{\"driver\": \"slab_ring_rt\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, \"steps\": %d, "
+                "\"ms_per_step\": %.4f, \"mlups\": %.1f, \"transport\": \"rccl send/recv (C++ ring)\"%s}\n",
+                world, R, C, a.steps, 1e3 * tmax / a.steps, (double)Rg * C * a.steps / tmax / 1e6,
+                a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
+    std::fflush(stdout);
+  }
+  lbm_ring_destroy(ring);
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 2; ++k) lbm_free(lat[b][k]);
+  return bad ? 3 : 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  Args a;
+  a.rows = std::atoi(arg_value(argc, argv, "--rows", "2048").c_str());
+  a.cols = std::atoi(arg_value(argc, argv, "--cols", "2048").c_str());
+  a.steps = std::atoi(arg_value(argc, argv, "--steps", "50").c_str());
+  a.warmup = std::atoi(arg_value(argc, argv, "--warmup", "5").c_str());
+  a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "16").c_str());
+  a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
+  a.id_file = arg_value(argc, argv, "--id-file", "/tmp/lbm_ring_id." + std::to_string((long)getpid()));
+  const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
+  try {
+    if (spawn > 0) {
+      const int rc = spawn_ranks(spawn, [&](int r) { return run_rank(a, r, spawn, r); });
+      cleanup_ring_files(a.id_file, spawn);
+      return rc;
+    }
+    const char* er = std::getenv("RANK");
+    const char* ew = std::getenv("WORLD_SIZE");
+    const char* el = std::getenv("LOCAL_RANK");
+    const int rank = er ? std::atoi(er) : 0, world = ew ? std::atoi(ew) : 1;
+    return run_rank(a, rank, world, el ? std::atoi(el) : rank);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "slab_ring_rt: %s\n", e.what());
+    return 1;
+  }
+}

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("LBM_HIP_LIB", os.path.join(PKG_DIR, "lib", "liblbm_hi
 HEADER = os.path.join(REPO, "include", "lbm_hip.h")
 
 EDGE_PERIODIC, EDGE_HALO, EDGE_BOUNCE_BACK, EDGE_SPECULAR, EDGE_ABB_VELOCITY, EDGE_WRAP_NOSHIFT = range(6)
+HALO_TWO_PHASE = -3  # lbm_halo_pack / _unpack depth code of the colour-gradient step (21 rows)
 MODEL_BGK, MODEL_KBC = 0, 1
 
 _dp = ct.POINTER(ct.c_double)

@@ -64,32 +64,44 @@ class _HaloTables(dict):
         return self[depth]
 
 
+def _halo_table_two_phase(outward):
+    """Colour-gradient step: 3 ghost rows as for a 3-step launch, but the second row travels
+    complete -- the driver's same-row column copy (mrtcg_rayleigh_taylor.cpp:517-523)
+    makes the column-0 / column-(C-1) nodes of ghost row 2 read {2,5,6} / {4,7,8} of their own
+    row.  9 + 9 + 3 = 21 rows per colour per side (C ABI: LBM_HALO_TWO_PHASE)."""
+    return [(ALL9, 0), (ALL9, 1), (outward, 2)]
+
+
+TWO_PHASE = "two_phase"
 HALO_TO_NEXT = _HaloTables(TO_NEXT)   # depth 1: [({1,5,8}, 0)]; depth 2: [({0,2,4,1,5,8}, 0), ({1,5,8}, 1)]; ...
 HALO_TO_PREV = _HaloTables(TO_PREV)
+HALO_TO_NEXT[TWO_PHASE] = _halo_table_two_phase(TO_NEXT)
+HALO_TO_PREV[TWO_PHASE] = _halo_table_two_phase(TO_PREV)
 # depth 3 = the colour-gradient step: pass A recomputes the macroscopic fields on ghost rows
 # -2..-1 (R..R+1), whose own streaming reaches one row further out.
 
 
-def halo_ops(lats, G, R, next_rank, prev_rank):
+def halo_ops(lats, G, R, next_rank, prev_rank, table=None):
     """P2P ops that bring the ghost rows of every lattice in `lats` (views [9, R+2G, C]) up to
     date.  Sends are issued (to next, to prev), receives (from prev, from next): with two ranks
     both neighbours are the same peer and messages match in issue order."""
     ops = []
+    T = G if table is None else table
     for f, lat in enumerate(lats):
         tag0 = 100 * f
         if next_rank is not None:   # my last rows -> their ghost rows above row 0
-            for pops, k in HALO_TO_NEXT[G]:
+            for pops, k in HALO_TO_NEXT[T]:
                 ops += [dist.P2POp(dist.isend, lat[q, G + R - 1 - k], next_rank, tag=tag0 + 10 * k + q) for q in pops]
         if prev_rank is not None:   # my first rows -> their ghost rows below row R-1
-            for pops, k in HALO_TO_PREV[G]:
+            for pops, k in HALO_TO_PREV[T]:
                 ops += [dist.P2POp(dist.isend, lat[q, G + k], prev_rank, tag=tag0 + 10 * k + q) for q in pops]
     for f, lat in enumerate(lats):
         tag0 = 100 * f
         if prev_rank is not None:
-            for pops, k in HALO_TO_NEXT[G]:
+            for pops, k in HALO_TO_NEXT[T]:
                 ops += [dist.P2POp(dist.irecv, lat[q, G - 1 - k], prev_rank, tag=tag0 + 10 * k + q) for q in pops]
         if next_rank is not None:
-            for pops, k in HALO_TO_PREV[G]:
+            for pops, k in HALO_TO_PREV[T]:
                 ops += [dist.P2POp(dist.irecv, lat[q, G + R + k], next_rank, tag=tag0 + 10 * k + q) for q in pops]
     return ops
 
@@ -317,7 +329,7 @@ class CgSlabRing:
     def exchange(self, lats):
         if not self.ghost:
             return []
-        ops = halo_ops(lats, self.ghost, self.R, self.next_rank, self.prev_rank)
+        ops = halo_ops(lats, self.ghost, self.R, self.next_rank, self.prev_rank, table=TWO_PHASE)
         return dist.batch_isend_irecv(ops) if ops else []
 
     def step(self, moments, collide_rows):

@@ -198,3 +198,85 @@ def test_static_droplet_preset_vs_oracle(lib, oracle, mode):
     p_in = (got["rho_r"][64, 64] * 3 * (1 - 0.7) / 5 + got["rho_b"][64, 64] * 3 * (1 - 0.1) / 5)
     p_out = (got["rho_r"][4, 4] * 3 * (1 - 0.7) / 5 + got["rho_b"][4, 4] * 3 * (1 - 0.1) / 5)
     assert np.isfinite(p_in - p_out)
+
+
+def test_cg_fused_two_slabs_equal_single_block(lib, oracle):
+    """The one-launch step over slabs: 2 slabs emulated on one GPU, 3 ghost rows per colour moved
+    with lbm_halo_pack / lbm_halo_unpack (the message the C++ ring sends: LBM_HALO_TWO_PHASE, 21 rows
+    per colour per side), edge rows before interior rows.  No macroscopic arrays exist on this path.  Must equal
+    the fused single block bit for bit (per-node arithmetic does not depend on the tiling), and
+    the oracle within the fused tolerance."""
+    import ctypes as ct
+    from gpu_util import dev, download_aos, upload_soa
+    from pylbm import _ptr
+    Rg, C, n, G = 96, 64, 12, 3
+    R = Rg // 2
+    po = pyoracle.cg_params(Rg, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    want = oracle.cg_steps(po, s0, n)
+    d = dev()
+    flat = pylbm.Geom(Rg, C, 0)
+    bc_flat = pylbm.Bc()
+    lib.raw.lbm_cg_default_bc(ct.byref(bc_flat))
+    f_r, f_b = upload_soa(lib, s0["f_r"]), upload_soa(lib, s0["f_b"])
+    rr, rb, uu = upload_soa(lib, s0["rho_r"]), upload_soa(lib, s0["rho_b"]), upload_soa(lib, s0["u"])
+    p = [torch.empty((9, Rg, C), dtype=torch.float64, device=d) for _ in range(2)]
+    lib.cg_collide(_ptr(p[0]), _ptr(p[1]), _ptr(f_r), _ptr(f_b), _ptr(rr), _ptr(rb), _ptr(uu),
+                   ct.byref(flat), ct.byref(bc_flat), ct.byref(pg), None, None, None)
+    torch.cuda.synchronize()
+    # single block, fused
+    q = [torch.empty_like(p[0]) for _ in range(2)]
+    a, b = [x.clone() for x in p], q
+    for _ in range(n - 1):
+        lib.cg_step_fused(_ptr(b[0]), _ptr(b[1]), _ptr(a[0]), _ptr(a[1]), ct.byref(flat), ct.byref(bc_flat),
+                          ct.byref(pg), 0, Rg, None, None, None, None, None, None)
+        a, b = b, a
+    torch.cuda.synchronize()
+    single = a
+    # two slabs
+    geom = pylbm.Geom(R, C, G)
+    bcs = []
+    for s in range(2):
+        bb = pylbm.Bc()
+        lib.raw.lbm_cg_default_bc(ct.byref(bb))
+        if s == 0:
+            bb.row_hi = pylbm.EDGE_HALO
+        else:
+            bb.row_lo = pylbm.EDGE_HALO
+        bcs.append(bb)
+    lat = [[[torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=d) for _ in range(2)]
+            for _ in range(2)] for _ in range(2)]          # [slab][buffer][colour]
+    H = pylbm.HALO_TWO_PHASE
+    rows = lib.raw.lbm_halo_rows(H)
+    assert rows == 21
+    msg = torch.empty(rows * C, dtype=torch.float64, device=d)
+
+    def halo(cur):
+        for k in range(2):
+            lib.halo_pack(_ptr(msg), _ptr(lat[0][cur][k]), ct.byref(geom), H, 1, None)    # slab 0 -> next
+            lib.halo_unpack(_ptr(lat[1][cur][k]), _ptr(msg), ct.byref(geom), H, 0, None)
+            lib.halo_pack(_ptr(msg), _ptr(lat[1][cur][k]), ct.byref(geom), H, 0, None)    # slab 1 -> previous
+            lib.halo_unpack(_ptr(lat[0][cur][k]), _ptr(msg), ct.byref(geom), H, 1, None)
+
+    for s in range(2):
+        for k in range(2):
+            lat[s][0][k][:, G:G + R] = p[k][:, s * R:(s + 1) * R]
+    halo(0)
+    cur = 0
+    for _ in range(n - 1):
+        for s in range(2):
+            src, dst = lat[s][cur], lat[s][cur ^ 1]
+            for r0, r1 in ((0, 16), (R - 16, R), (16, R - 16)):
+                lib.cg_step_fused(_ptr(dst[0]), _ptr(dst[1]), _ptr(src[0]), _ptr(src[1]), ct.byref(geom),
+                                  ct.byref(bcs[s]), ct.byref(pg), r0, r1, None, None, None, None, None, None)
+        cur ^= 1
+        halo(cur)
+    torch.cuda.synchronize()
+    out = torch.empty_like(p[0])
+    for k, key in ((0, "f_r"), (1, "f_b")):
+        P = torch.cat([lat[0][cur][k][:, G:G + R], lat[1][cur][k][:, G:G + R]], dim=1).contiguous()
+        assert torch.equal(P, single[k]), key
+        lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc_flat), None)
+        got = download_aos(lib, out)
+        assert relerr(got, want[key]) < 1e-11, (key, relerr(got, want[key]))

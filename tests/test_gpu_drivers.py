@@ -149,3 +149,18 @@ def test_slab_ring_box_driver_self_ring(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["check"] == "bitwise equal to one block" and line["depth"] == depth
+
+
+def test_slab_ring_rt_driver(tmp_path):
+    """C++ host of config 4 over slabs (drivers/slab_ring_rt.cpp on lbm_ring_cg_step): with one rank the
+    chain has no neighbour, so this checks the slab-geometry path (3 ghost rows, walls on the slab)
+    against the ghost-free single block bit for bit; the exchange itself is covered by
+    test_cg_fused_two_slabs_equal_single_block and the BGK self-ring tests."""
+    import json
+    exe = os.path.join(BIN, "slab_ring_rt")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--spawn", "1", "--rows", "128", "--cols", "64", "--steps", "8", "--warmup", "2",
+                        "--check", "1", "--id-file", str(tmp_path / "id")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block"

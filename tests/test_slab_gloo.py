@@ -180,8 +180,8 @@ def test_colour_gradient_ring_exchange_depth3(tmp_path):
             for q in range(9):
                 for k in range(3):
                     above, below = a[q, G - 1 - k, 0], a[q, G + R + k, 0]
-                    need_above = any(q in pops and kk == k for pops, kk in HALO_TO_NEXT[3])
-                    need_below = any(q in pops and kk == k for pops, kk in HALO_TO_PREV[3])
+                    need_above = any(q in pops and kk == k for pops, kk in HALO_TO_NEXT["two_phase"])
+                    need_below = any(q in pops and kk == k for pops, kk in HALO_TO_PREV["two_phase"])
                     # chain: no neighbour beyond the first / last slab -> ghost rows untouched
                     assert above == (val(rank - 1, f, q, R - 1 - k) if rank > 0 and need_above else -1.0)
                     assert below == (val(rank + 1, f, q, k) if rank < world - 1 and need_below else -1.0)
