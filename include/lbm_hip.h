@@ -298,6 +298,11 @@ int lbm_ibm_force(lbm_ibm* ib, const double* u, const double* rho, double* F_out
  * p[q][roi] += (1 - omega/2) w_q [ (a + b c_q.u)(c_q.F) - a u.F ]  with the UNcorrected u */
 int lbm_ibm_add_source(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, double omega,
                        double a, double b, lbm_stream_t s);
+/* lbm_ibm_force + lbm_ibm_add_source of one time step as ONE launch of one workgroup (the 2 (m_max-1)
+ * + 2 small dependent launches are a latency chain otherwise); bit-identical results.  What the
+ * solver context and the slab ring call. */
+int lbm_ibm_step(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, const double* rho,
+                 double omega, double a, double b, lbm_stream_t s);
 /* F_s = sum over the ROI of F (drag, lift), cylinder_test.cpp:112; host out[2], synchronises */
 int lbm_ibm_surface_force(lbm_ibm* ib, double* out2, lbm_stream_t s);
 
@@ -360,6 +365,14 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
 int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* src_r,
                      const double* src_b, const lbm_bc* bc, const lbm_cg_params* prm, int edge_rows,
                      lbm_stream_t main);
+
+/* one overlapped single-step launch of a BGK slab that may own an immersed boundary (config 5 over
+ * slabs): as lbm_ring_bgk_step with n_steps = 1, plus -- on the rank whose slab contains the ROI
+ * (ib from lbm_ibm_create_slab; NULL elsewhere) -- rho / u written for the ROI rows only,
+ * lbm_ibm_force and the Guo source on dst.  rho [R][C], u [2][R][C] slab-local. */
+int lbm_ring_bgk_step_ibm(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                          const lbm_bgk_params* prm, int edge_rows, lbm_ibm* ib, double guo_a,
+                          double guo_b, double* rho, double* u, lbm_stream_t main);
 
 /* ---- snapshots and checkpoints (the reference only torch::save()s snapshot
  * stacks at the end of a run, e.g. horizontal_poiseuille_test.cpp:157-160) ------------------------ */

@@ -25,6 +25,10 @@ struct IbmDev {
   const int* csr_ptr;  // [RR*RC + 1]
   const int* csr_mk;   // [nnz] marker of each (node, tap) pair, ascending per node
   const double* csr_w; // [nnz] its weight phi
+  const int* touched;  // [n_touched] ROI-flat indices of the nodes with at least one tap
+  int n_touched;
+  const int* tap_t;    // [n_markers][16] index into `touched` of each marker tap
+  const int* tptr;     // [n_touched + 1] csr_ptr restricted to the touched nodes
 };
 
 // u, rho of the ROI window copied out of the full fields (ibm.cpp:163-164); F_sum = 0
@@ -110,6 +114,101 @@ __global__ __launch_bounds__(256) void k_ibm_add_source(IbmDev d, double* __rest
   }
 }
 
+// The whole forcing of one time step in ONE launch of ONE workgroup: eulerian_force_density
+// (ibm.cpp:158-190, all m_max - 1 iterations) followed by the driver's source term
+// (cylinder_test.cpp:116-127).  Only the nodes under a marker's 4x4 box ("touched", a band of a
+// few thousand nodes) take part: elsewhere F = 0, u is never read again and the source is exactly
+// 0.  The separate kernels above cost 2 (m_max - 1) + 2 dependent launches of microseconds of work
+// each -- a ~0.1 ms latency chain per step; here the phases are separated by workgroup barriers
+// and the working set (u, rho of the touched nodes, f_j of the markers) lives in LDS.
+// Arithmetic per marker / per node is that of k_ibm_interp / k_ibm_spread / k_ibm_add_source in
+// the same order, so results are bit-identical.  Dynamic LDS: (3 n_touched + 2 n_markers) doubles.
+__global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const double* __restrict__ u,
+                                                   const double* __restrict__ rho,
+                                                   double* __restrict__ F_sum, double* __restrict__ p,
+                                                   Geom g, double omega, double a, double b,
+                                                   int with_source) {
+  extern __shared__ double lds[];
+  const int nt = d.n_touched, nm = d.n_markers, n = d.RR * d.RC;
+  double* s_ux = lds;            // [nt]
+  double* s_uy = lds + nt;       // [nt]
+  double* s_rho = lds + 2 * nt;  // [nt]
+  double* s_fj = lds + 3 * nt;   // [2 nm]
+  const long N = (long)d.X * d.Y;
+  // each thread owns the touched nodes t = tid, tid + 1024, ...: F accumulates in registers
+  constexpr int MAXOWN = 8;  // host guarantees nt <= 8 * 1024
+  double Fx[MAXOWN], Fy[MAXOWN];
+#pragma unroll
+  for (int k = 0; k < MAXOWN; ++k) {
+    Fx[k] = 0.0;
+    Fy[k] = 0.0;
+    const int t = threadIdx.x + k * 1024;
+    if (t < nt) {
+      const int i = d.touched[t];
+      const long s = (long)(d.r0 + i / d.RC) * d.Y + (d.c0 + i % d.RC);
+      s_ux[t] = u[s];
+      s_uy[t] = u[N + s];
+      s_rho[t] = rho[s];
+    }
+  }
+  __syncthreads();
+  for (int it = 1; it < m_max; ++it) {
+    for (int j = threadIdx.x; j < nm; j += 1024) {
+      double ujx = 0.0, ujy = 0.0, rhoj = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int t = d.tap_t[j * 16 + k];
+        const double w = d.phi[j * 16 + k];
+        ujx += w * s_ux[t];
+        ujy += w * s_uy[t];
+        rhoj += w * s_rho[t];
+      }
+      s_fj[j] = -2.0 * rhoj * ujx;
+      s_fj[nm + j] = -2.0 * rhoj * ujy;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAXOWN; ++k) {
+      const int t = threadIdx.x + k * 1024;
+      if (t < nt) {
+        double fx = 0.0, fy = 0.0;
+        for (int e = d.tptr[t]; e < d.tptr[t + 1]; ++e) {
+          const int j = d.csr_mk[e];
+          const double w = d.csr_w[e];
+          fx += w * s_fj[j];
+          fy += w * s_fj[nm + j];
+        }
+        const double rh = s_rho[t];
+        s_ux[t] += 0.5 * fx / rh;
+        s_uy[t] += 0.5 * fy / rh;
+        Fx[k] += fx;
+        Fy[k] += fy;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < MAXOWN; ++k) {
+    const int t = threadIdx.x + k * 1024;
+    if (t >= nt) continue;
+    const int i = d.touched[t];
+    F_sum[i] = Fx[k];
+    F_sum[n + i] = Fy[k];
+    if (!with_source) continue;
+    const int r = d.r0 + i / d.RC, c = d.c0 + i % d.RC;
+    const long s = (long)r * d.Y + c;
+    const double ux = u[s], uy = u[N + s];
+    const double uF = ux * Fx[k] + uy * Fy[k];
+    const long o = g.at(r, c);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+      const double cF = Fx[k] * (double)icx(q) + Fy[k] * (double)icy(q);
+      p[q * g.plane + o] += ((1 - 0.5 * omega) * ((a + b * cu) * cF - a * uF) * wq(q));
+    }
+  }
+}
+
 // F_s = F.reshape(-1, 2).sum(0): one block, fixed-order tree -> reproducible
 __global__ __launch_bounds__(256) void k_ibm_sum(int n, const double* __restrict__ F_sum,
                                                  double* __restrict__ out2) {
@@ -140,6 +239,7 @@ __global__ __launch_bounds__(256) void k_ibm_sum(int n, const double* __restrict
 struct lbm_ibm {
   lbm::IbmDev d;
   int m_max, r1, c1;
+  bool lds_opt_in = false;
   void* dev_blob;                  // all constant device arrays in one allocation
   double *u_roi, *rho_roi, *F_sum, *fj, *out2;  // device work arrays
 };
@@ -201,6 +301,21 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
     csr_ptr[i + 1] = (int)csr_mk.size();
   }
   const size_t nnz = csr_mk.size();
+  // the nodes under at least one box, in ROI order; per-tap index into that list; CSR offsets of
+  // those nodes (entries of consecutive touched nodes are NOT contiguous in csr_mk: keep begin/end
+  // by storing ptr of the node and relying on csr_ptr[i + 1] of the same node)
+  std::vector<int> touched, t_of(n, -1);
+  for (int i = 0; i < n; ++i)
+    if (csr_ptr[i + 1] > csr_ptr[i]) {
+      t_of[i] = (int)touched.size();
+      touched.push_back(i);
+    }
+  std::vector<int> tap_t((size_t)n_markers * 16), tptr(touched.size() + 1);
+  for (int j = 0; j < n_markers; ++j)
+    for (int k = 0; k < 16; ++k) tap_t[(size_t)j * 16 + k] = t_of[box0[j] + (k / 4) * RC + (k % 4)];
+  // untouched nodes have empty CSR rows, so the touched nodes' entries ARE contiguous and in order
+  for (size_t t = 0; t < touched.size(); ++t) tptr[t] = csr_ptr[touched[t]];
+  tptr[touched.size()] = (int)nnz;
 
   lbm_ibm* ib = new (std::nothrow) lbm_ibm();
   LBM_REQUIRE(ib, "lbm_ibm_create: out of host memory");
@@ -210,7 +325,7 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   ib->dev_blob = nullptr;
   ib->u_roi = ib->rho_roi = ib->F_sum = ib->fj = ib->out2 = nullptr;
   // one blob: doubles first (8-byte aligned), then ints
-  const size_t n_dbl = phi.size() + nnz, n_int = box0.size() + csr_ptr.size() + nnz;
+  const size_t n_dbl = phi.size() + nnz, n_int = box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size() + tptr.size();
   const size_t blob_bytes = n_dbl * 8 + n_int * 4;
   std::vector<char> host(blob_bytes);
   double* hd = reinterpret_cast<double*>(host.data());
@@ -220,11 +335,15 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   std::copy(box0.begin(), box0.end(), hi);
   std::copy(csr_ptr.begin(), csr_ptr.end(), hi + box0.size());
   std::copy(csr_mk.begin(), csr_mk.end(), hi + box0.size() + csr_ptr.size());
+  std::copy(touched.begin(), touched.end(), hi + box0.size() + csr_ptr.size() + nnz);
+  std::copy(tap_t.begin(), tap_t.end(), hi + box0.size() + csr_ptr.size() + nnz + touched.size());
+  std::copy(tptr.begin(), tptr.end(), hi + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size());
   hipError_t e = hipMalloc(&ib->dev_blob, blob_bytes);
   if (e == hipSuccess) e = hipMemcpy(ib->dev_blob, host.data(), blob_bytes, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&ib->u_roi, (size_t)n * 16);
   if (e == hipSuccess) e = hipMalloc(&ib->rho_roi, (size_t)n * 8);
   if (e == hipSuccess) e = hipMalloc(&ib->F_sum, (size_t)n * 16);
+  if (e == hipSuccess) e = hipMemset(ib->F_sum, 0, (size_t)n * 16);  // k_ibm_step writes touched nodes only
   if (e == hipSuccess) e = hipMalloc(&ib->fj, (size_t)n_markers * 16);
   if (e == hipSuccess) e = hipMalloc(&ib->out2, 16);
   if (e != hipSuccess) {
@@ -236,7 +355,10 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   const double* dd = reinterpret_cast<const double*>(base);
   const int* di = reinterpret_cast<const int*>(base + n_dbl * 8);
   ib->d = IbmDev{n_markers, RR, RC, (int)r_min - row_offset, (int)c_min, X, Y, di, dd,
-                 di + box0.size(), di + box0.size() + csr_ptr.size(), dd + phi.size()};
+                 di + box0.size(), di + box0.size() + csr_ptr.size(), dd + phi.size(),
+                 di + box0.size() + csr_ptr.size() + nnz, (int)touched.size(),
+                 di + box0.size() + csr_ptr.size() + nnz + touched.size(),
+                 di + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size()};
   *out = ib;
   return LBM_OK;
 }
@@ -288,6 +410,28 @@ int lbm_ibm_add_source(lbm_ibm* ib, double* p, const lbm_geom* g, const double* 
   const int n = ib->d.RR * ib->d.RC;
   LBM_KLAUNCH(k_ibm_add_source, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), ib->d, p,
               make_geom(*g), u, ib->F_sum, omega, a, b);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_ibm_step(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, const double* rho,
+                 double omega, double a, double b, lbm_stream_t s) {
+  LBM_REQUIRE(ib && p && g && u && rho, "lbm_ibm_step: NULL argument");
+  LBM_REQUIRE(g->R == ib->d.X && g->C == ib->d.Y,
+              "lbm_ibm_step: lattice %dx%d does not match the boundary's %dx%d", g->R, g->C, ib->d.X, ib->d.Y);
+  const size_t lds = ((size_t)3 * ib->d.n_touched + 2 * (size_t)ib->d.n_markers) * sizeof(double);
+  if (ib->d.n_touched > 8 * 1024 || lds > 150 * 1024) {  // large boundaries: the launch chain
+    int rc = lbm_ibm_force(ib, u, rho, nullptr, s);
+    if (!rc) rc = lbm_ibm_add_source(ib, p, g, u, omega, a, b, s);
+    return rc;
+  }
+  if (!ib->lds_opt_in) {
+    LBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ibm_step),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ib->lds_opt_in = true;
+  }
+  LBM_KLAUNCH(k_ibm_step, dim3(1), dim3(1024), lds, as_stream(s), ib->d, ib->m_max, u, rho, ib->F_sum, p,
+              make_geom(*g), omega, a, b, 1);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }

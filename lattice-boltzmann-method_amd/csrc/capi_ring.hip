@@ -83,7 +83,8 @@ struct lbm_ring {
   lbm_geom g;                    // slab geometry (ghost = halo depth)
   size_t msg;                    // doubles per packed message
   hipStream_t edge;              // edge rows, pack, send/recv, unpack
-  hipEvent_t main_done, edge_done;
+  hipStream_t aux;               // immersed-boundary rows + forcing chain (created on first use)
+  hipEvent_t main_done, edge_done, aux_done;
   double *send_next, *send_prev, *recv_prev, *recv_next;
 };
 
@@ -150,6 +151,11 @@ int lbm_ring_destroy(lbm_ring* rg) {
     if (p) (void)hipFree(p);
   if (rg->main_done) (void)hipEventDestroy(rg->main_done);
   if (rg->edge_done) (void)hipEventDestroy(rg->edge_done);
+  if (rg->aux_done) (void)hipEventDestroy(rg->aux_done);
+  if (rg->aux) {
+    (void)hipStreamSynchronize(rg->aux);
+    (void)hipStreamDestroy(rg->aux);
+  }
   if (rg->edge) (void)hipStreamDestroy(rg->edge);
   if (rg->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(rg->comm);
   delete rg;
@@ -281,6 +287,74 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   if (rc) return rc;
   LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
   LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+  return LBM_OK;
+}
+
+// One overlapped single-step launch of a BGK slab that may own an immersed boundary (config 5:
+// cylinder_test.cpp:88-164 over slabs).  Three concurrent chains:
+//   edge stream : the rows at both slab ends, then the halo exchange of dst;
+//   aux stream  : (owning rank) the ROI rows with rho, u -> multi-direct forcing (lbm_ibm_force,
+//                 ~10 small dependent launches) -> Guo source on the ROI of dst (:110-127);
+//   main stream : every other row.
+// The forcing chain is latency-bound (~0.3 ms for 942 markers) and would otherwise serialise
+// behind the lattice update on the one rank that owns the boundary -- the straggler of a weak-
+// scaling run.  The ROI never contains a slab's first or last row, so the rows that travel
+// carry no source.  ib = NULL: ranks that do not own the boundary (rho, u unused).
+// rho [R][C], u [2][R][C], written on the ROI rows only.
+int lbm_ring_bgk_step_ibm(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                          const lbm_bgk_params* prm, int edge_rows, lbm_ibm* ib, double guo_a,
+                          double guo_b, double* rho, double* u, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_bgk_step_ibm: NULL argument");
+  LBM_REQUIRE(!ib || (rho && u), "lbm_ring_bgk_step_ibm: the owning rank needs rho and u buffers");
+  const int R = rg->g.R, G = rg->g.ghost;
+  LBM_REQUIRE(G >= 1, "lbm_ring_bgk_step_ibm: slab without ghost rows");
+  if (edge_rows < 1) edge_rows = 1;
+  LBM_REQUIRE(2 * edge_rows < R, "lbm_ring_bgk_step_ibm: edge_rows=%d too large for %d rows", edge_rows, R);
+  hipStream_t main = as_stream(main_s);
+  lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
+  if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
+  if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  int q0 = 0, q1 = 0, c0 = 0, c1 = 0;  // ROI rows [q0, q1)
+  if (ib) {
+    int rc = lbm_ibm_roi(ib, &q0, &q1, &c0, &c1);
+    if (rc) return rc;
+    LBM_REQUIRE(q0 >= 1 && q1 <= R - 1 && q0 < q1, "lbm_ring_bgk_step_ibm: ROI rows [%d, %d) touch the slab edge", q0, q1);
+    if (!rg->aux) {
+      int lo = 0, hi = 0;
+      LBM_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      LBM_CHECK_HIP(hipStreamCreateWithPriority(&rg->aux, hipStreamNonBlocking, hi));
+      LBM_CHECK_HIP(hipEventCreateWithFlags(&rg->aux_done, hipEventDisableTiming));
+    }
+  }
+  auto rows = [&](int r0, int r1, bool mom, hipStream_t st) -> int {
+    if (r0 >= r1) return LBM_OK;
+    return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, mom ? rho : nullptr, mom ? u : nullptr, st);
+  };
+  // rows [r0, r1) minus the ROI rows (which the aux chain computes)
+  auto rows_outside_roi = [&](int r0, int r1, hipStream_t st) -> int {
+    if (!ib || q1 <= r0 || q0 >= r1) return rows(r0, r1, false, st);
+    int rc = rows(r0, q0 < r0 ? r0 : q0, false, st);
+    if (!rc) rc = rows(q1 > r1 ? r1 : q1, r1, false, st);
+    return rc;
+  };
+  LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
+  LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+  int rc = rows_outside_roi(0, edge_rows, rg->edge);
+  if (!rc) rc = rows_outside_roi(R - edge_rows, R, rg->edge);
+  if (!rc) rc = ring_exchange(rg, dst, nullptr, rg->edge);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+  if (ib) {
+    LBM_CHECK_HIP(hipStreamWaitEvent(rg->aux, rg->main_done, 0));
+    rc = rows(q0, q1, true, rg->aux);
+    if (!rc) rc = lbm_ibm_step(ib, dst, &rg->g, u, rho, prm->omega, guo_a, guo_b, rg->aux);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipEventRecord(rg->aux_done, rg->aux));
+  }
+  rc = rows_outside_roi(edge_rows, R - edge_rows, main);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+  if (ib) LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->aux_done, 0));
   return LBM_OK;
 }
 

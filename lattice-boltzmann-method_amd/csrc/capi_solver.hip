@@ -27,6 +27,8 @@ struct lbm_solver {
   long steps;
   lbm_ibm* ibm;  // optional immersed boundary (not owned)
   double guo_a, guo_b;
+  hipStream_t side = nullptr;  // forcing chain of the immersed boundary, beside the lattice update
+  hipEvent_t ev_roi = nullptr, ev_ibm = nullptr;
 };
 
 using namespace lbm;
@@ -38,9 +40,29 @@ static int solver_collide_first(lbm_solver* sv, double* rho, double* u) {
     return lbm_bgk_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, rho, u, sv->st);
   return lbm_kbc_collide(dst, src, &sv->g, &sv->bc, &sv->kbc, rho, u, sv->st);
 }
-static int solver_fused(lbm_solver* sv, double* rho, double* u) {
+// with_ibm_overlap: the moments are wanted for the immersed boundary alone -> the ROI rows go first
+// (rho, u written there only: saves the 24 B per node of a full store), the forcing + source
+// (lbm_ibm_step, one latency-bound workgroup) runs on a side stream while the main stream updates
+// the rows above and below the ROI.  Returns with the forcing joined back into sv->st.
+static int solver_fused(lbm_solver* sv, double* rho, double* u, bool with_ibm_overlap = false) {
   double* dst = sv->lat[sv->cur ^ 1];
   const double* src = sv->lat[sv->cur];
+  if (sv->model == LBM_MODEL_BGK && with_ibm_overlap && sv->ibm && sv->side) {
+    int q0, q1, c0, c1;
+    int rc = lbm_ibm_roi(sv->ibm, &q0, &q1, &c0, &c1);
+    if (!rc) rc = lbm_bgk_stream_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, q0, q1, rho, u, sv->st);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipEventRecord(sv->ev_roi, sv->st));
+    LBM_CHECK_HIP(hipStreamWaitEvent(sv->side, sv->ev_roi, 0));
+    rc = lbm_ibm_step(sv->ibm, dst, &sv->g, u, rho, sv->bgk.omega, sv->guo_a, sv->guo_b, sv->side);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipEventRecord(sv->ev_ibm, sv->side));
+    rc = lbm_bgk_stream_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, q1, sv->g.R, nullptr, nullptr, sv->st);
+    if (!rc) rc = lbm_bgk_stream_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, 0, q0, nullptr, nullptr, sv->st);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipStreamWaitEvent(sv->st, sv->ev_ibm, 0));
+    return LBM_OK;
+  }
   if (sv->model == LBM_MODEL_BGK)
     return lbm_bgk_stream_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, 0, sv->g.R, rho, u, sv->st);
   return lbm_kbc_stream_collide(dst, src, &sv->g, &sv->bc, &sv->kbc, 0, sv->g.R, rho, u, sv->st);
@@ -94,6 +116,12 @@ int lbm_solver_destroy(lbm_solver* sv) {
   if (!sv) return LBM_OK;
   for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u})
     if (p) (void)hipFree(p);
+  if (sv->side) {
+    (void)hipStreamSynchronize(sv->side);
+    (void)hipStreamDestroy(sv->side);
+  }
+  if (sv->ev_roi) (void)hipEventDestroy(sv->ev_roi);
+  if (sv->ev_ibm) (void)hipEventDestroy(sv->ev_ibm);
   delete sv;
   return LBM_OK;
 }
@@ -182,20 +210,21 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
     }
     {
     // with an immersed boundary every step needs this step's rho, u (cylinder_test.cpp:110)
-    const bool rec = (record_moments && i == n - 1) || sv->ibm;
-    int rc = sv->post ? solver_fused(sv, rec ? sv->rho : nullptr, rec ? sv->u : nullptr)
+    const bool want = record_moments && i == n - 1;  // the caller's full-field moments
+    const bool first = !sv->post;                    // the collide-only step writes full fields
+    const bool rec = want || sv->ibm;
+    const bool overlap = sv->post && sv->ibm && sv->side && !want;  // forcing done inside solver_fused
+    int rc = sv->post ? solver_fused(sv, rec ? sv->rho : nullptr, rec ? sv->u : nullptr, overlap)
                       : solver_collide_first(sv, rec ? sv->rho : nullptr, rec ? sv->u : nullptr);
     if (rc) return rc;
-    if (sv->ibm) {  // :110-127: F = ib.eulerian_force_density(u, rho); f_coll[ROI] += S(u, F)
-      rc = lbm_ibm_force(sv->ibm, sv->u, sv->rho, nullptr, sv->st);
-      if (rc) return rc;
-      rc = lbm_ibm_add_source(sv->ibm, sv->lat[sv->cur ^ 1], &sv->g, sv->u, sv->bgk.omega,
-                              sv->guo_a, sv->guo_b, sv->st);
+    if (sv->ibm && !overlap) {  // :110-127: F = ib.eulerian_force_density(u, rho); f_coll[ROI] += S(u, F)
+      rc = lbm_ibm_step(sv->ibm, sv->lat[sv->cur ^ 1], &sv->g, sv->u, sv->rho, sv->bgk.omega,
+                        sv->guo_a, sv->guo_b, sv->st);
       if (rc) return rc;
     }
     sv->cur ^= 1;
     sv->post = true;
-    if (rec) sv->have_moments = true;
+    if (rec) sv->have_moments = want || first || !overlap;  // a ROI-windowed step leaves the full fields stale
     ++sv->steps;
     ++i;
     }
@@ -228,6 +257,11 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
                 "lbm_solver_attach_ibm: ROI must lie strictly inside the lattice");
   }
   sv->ibm = ib;
+  if (ib && !sv->side) {
+    LBM_CHECK_HIP(hipStreamCreateWithFlags(&sv->side, hipStreamNonBlocking));
+    LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_roi, hipEventDisableTiming));
+    LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_ibm, hipEventDisableTiming));
+  }
   sv->guo_a = guo_a;
   sv->guo_b = guo_b;
   return LBM_OK;

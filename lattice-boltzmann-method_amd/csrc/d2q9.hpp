@@ -618,13 +618,14 @@ template <class Model, bool WITH_MOMENTS>
 __global__ __launch_bounds__(256) void k_edge_stream_collide(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Bc bc, Model m, int row_begin,
     int row_end, double* __restrict__ rho_out, double* __restrict__ u_out) {
-  // edge list: [0, C) row 0 | [C, 2C) row R-1 | [2C, 2C+R) col 0 | [2C+R, 2C+2R) col C-1
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // edge list of the row range (n = row_end - row_begin):
+  // [0, C) row 0 | [C, 2C) row R-1 | [2C, 2C+n) col 0 | [2C+n, 2C+2n) col C-1
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, n = row_end - row_begin;
   int r, c;
   if (i < g.C) { r = 0; c = i; }
   else if (i < 2 * g.C) { r = g.R - 1; c = i - g.C; }
-  else if (i < 2 * g.C + g.R) { r = i - 2 * g.C; c = 0; }
-  else if (i < 2 * g.C + 2 * g.R) { r = i - 2 * g.C - g.R; c = g.C - 1; }
+  else if (i < 2 * g.C + n) { r = row_begin + i - 2 * g.C; c = 0; }
+  else if (i < 2 * g.C + 2 * n) { r = row_begin + i - 2 * g.C - n; c = g.C - 1; }
   else return;
   if (r < row_begin || r >= row_end) return;
   if (i >= 2 * g.C && (r == 0 || r == g.R - 1)) return;  // corners belong to the row lists

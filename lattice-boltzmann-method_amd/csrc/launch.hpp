@@ -107,7 +107,7 @@ int launch_stream_collide(const char* fn, double* pn, const double* po, const lb
   LBM_CHECK_LAUNCH();
 
   if (bc_needs_edge_pass(bc)) {
-    const int n_edge = 2 * g.C + 2 * g.R;
+    const int n_edge = 2 * g.C + 2 * (row_end - row_begin);
     if (mom) LBM_KLAUNCH((k_edge_stream_collide<Model, true>), dim3((n_edge + 255) / 256), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
     else LBM_KLAUNCH((k_edge_stream_collide<Model, false>), dim3((n_edge + 255) / 256), dim3(256), 0, st, pn, po, g, bc, m, row_begin, row_end, rho, u);
     LBM_CHECK_LAUNCH();

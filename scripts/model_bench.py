@@ -114,7 +114,7 @@ def bench_cylinder(X, Y, n=30):
     lib.solver_set_f_soa_dev(sv.h, _ptr(f))
     del f, u, rho
     dt = timed(lambda k: sv.step(k), n)
-    report("BGK + IBM cylinder (d=300, %d markers)" % m, X, Y, dt, 144, dict(note="+24 B/LUP moment output every step"))
+    report("BGK + IBM cylinder (d=300, %d markers)" % m, X, Y, dt, 144, dict(note="rho, u written on the ROI rows only; forcing (one workgroup) overlapped on a side stream"))
     sv.close(); ib.close()
 
 

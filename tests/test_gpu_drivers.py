@@ -164,3 +164,20 @@ def test_slab_ring_rt_driver(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["check"] == "bitwise equal to one block"
+
+
+def test_slab_ring_cylinder_driver(tmp_path):
+    """C++ host of config 5 over slabs (drivers/slab_ring_cylinder.cpp on lbm_ring_bgk_step_ibm): slab
+    geometry with a ghost row, moments written for the ROI rows only, forcing overlapped with the halo
+    stream.  --check: populations and surface force equal the single-block solver-context run bit for
+    bit.  (One rank: the chain has no neighbour; the exchange is covered by the self-ring tests.)"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_cylinder")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "--spawn", "1", "--rows", "192", "--cols", "160", "--diameter", "30", "--steps", "12",
+                        "--warmup", "3", "--edge-rows", "8", "--check", "1", "--id-file", str(tmp_path / "id")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block"
+    assert line["markers"] == 94 and abs(line["Fs"][0]) > 0
