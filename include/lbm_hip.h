@@ -195,6 +195,15 @@ int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
 int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
                            const lbm_bc* bc, const lbm_kbc_params* prm, int row_begin,
                            int row_end, double* rho, double* u, lbm_stream_t s);
+/* First iteration of a driver that HOLDS its moments (test/ulbm_poiseuille.cpp:85-86 starts from
+ * adve_f = 0 with m0 = 1, m1 = 0): kbc::collide() on the given (m0 [R][C], m1 [2][R][C]) instead of
+ * the populations' own moments, single block.  With bc->pressure_rows the KBC flavour of the
+ * pressure-periodic rows is applied (ulbm_poiseuille.cpp:36-58: solver::incomp_equilibrium for the
+ * imposed density, kbc.iequi_f.pow(-1) as f_equi); lbm_kbc_stream_collide applies it on the later
+ * iterations. */
+int lbm_kbc_collide_first(double* p, const double* f, const double* m0, const double* m1,
+                          const lbm_geom* g, const lbm_bc* bc, const lbm_kbc_params* prm,
+                          lbm_stream_t s);
 
 /* ---- colour-gradient two-phase MRT (test/mrtcg_rayleigh_taylor.cpp; BASELINE config 4) ----
  * Two passes per step over post-collision populations of both colours:
@@ -322,6 +331,9 @@ int lbm_solver_set_f_aos(lbm_solver* sv, const double* f_host);
 int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host);
 /* same, device SoA [9][R][C] (no ghost rows) */
 int lbm_solver_set_f_soa_dev(lbm_solver* sv, const double* f_dev);
+/* KBC only, after set_f: the first iteration collides on these moments (host AoS rho [R][C],
+ * u [R][C][2]) instead of the populations' own -- drivers that hold m0 / m1 (ulbm_poiseuille.cpp) */
+int lbm_solver_set_moments_aos(lbm_solver* sv, const double* rho_host, const double* u_host);
 int lbm_solver_get_f_soa_dev(lbm_solver* sv, double* f_dev);
 /* n driver iterations; record_moments != 0: the last one also stores rho/u exactly as the
  * reference's rho/u tensors hold them when its loop has run n iterations */

@@ -37,6 +37,80 @@ __global__ __launch_bounds__(256) void k_kbc_collide_given(double* __restrict__ 
   }
 }
 
+// the same on a lattice with its own plane stride (solver context); m0 [R][C], m1 [2][R][C] dense
+__global__ __launch_bounds__(256) void k_kbc_collide_first(double* __restrict__ pn,
+                                                           const double* __restrict__ in, Geom g,
+                                                           const double* __restrict__ m0,
+                                                           const double* __restrict__ m1, KbcModel m) {
+  const long n = (long)g.R * g.C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long o = g.at((int)(i / g.C), (int)(i % g.C));
+    double v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) v[q] = in[q * g.plane + o];
+    m.collide_with(v, m0[i], m1[i], m1[n + i]);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) pn[q * g.plane + o] = v[q];
+  }
+}
+
+// Pressure-periodic virtual rows of test/ulbm_poiseuille.cpp:36-58: row 0 <- feq_inc(rho_inlet,
+// u[R-2]) + f_coll[R-2] - f_equi[R-2], row R-1 <- feq_inc(rho_outlet, u[1]) + f_coll[1] - f_equi[1],
+// where feq_inc is solver::incomp_equilibrium (:50,:54) and f_equi = kbc.iequi_f.pow(-1) (:122),
+// i.e. the reciprocal of the reciprocal the collision stored -- kept as two divisions.
+// MODE 0: `in` is the pre-collision state and the moments are GIVEN (first iteration of the
+// driver, which starts from adve_f = 0 with m0 = 1; "dense single block" above refers to m0/m1); MODE 1: `in` holds post-collision
+// populations, streamed at read time, moments recomputed (:136-139).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_kbc_pressure_rows(double* __restrict__ pn,
+                                                           const double* __restrict__ in, Geom g,
+                                                           Bc bc, KbcModel m,
+                                                           const double* __restrict__ m0,
+                                                           const double* __restrict__ m1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * g.C) return;
+  const int e = i / g.C, c = i % g.C;
+  const int dst = e ? g.R - 1 : 0, src = e ? 1 : g.R - 2;
+  const double rho_bc = (e ? bc.rho_outlet : bc.rho_inlet) * 1.0;
+  double f[Q], fe[Q], te[Q], rho, ux, uy;
+  if (MODE == 1) {
+    gather_bc(f, in, g, bc, src, c);
+    double jx, jy;
+    BgkModel::moments(f, rho, jx, jy);
+    ux = jx / rho;
+    uy = jy / rho;
+  } else {
+#pragma unroll
+    for (int q = 0; q < Q; ++q) f[q] = in[q * g.plane + g.at(src, c)];
+    const long n = (long)g.R * g.C, o = (long)src * g.C + c;
+    rho = m0[o];
+    ux = m1[o];
+    uy = m1[n + o];
+  }
+  KbcModel::feq_poly(fe, ux, uy, ux * ux, uy * uy);  // eval_iequilibrium :230-246
+#pragma unroll
+  for (int q = 0; q < Q; ++q) fe[q] = 1.0 / (1.0 / (fe[q] * rho));
+  m.collide_with(f, rho, ux, uy);
+  const BgkModel inc{1.0, 1, 0, 0, 0.0, 0.0, 0.0, 0.0};
+  inc.feq(te, rho_bc, ux, uy);
+  const long o = g.at(dst, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) pn[q * g.plane + o] = (te[q] + f[q]) - fe[q];
+}
+
+static int launch_kbc_pressure_rows(int mode, double* pn, const double* in, const lbm_geom* lg,
+                                    const lbm_bc* lbc, const KbcModel& m, const double* m0,
+                                    const double* m1, hipStream_t st) {
+  LBM_REQUIRE(lg->ghost == 0 && pn != in, "lbm_kbc: pressure rows need a single block and distinct lattices");
+  const Geom g = make_geom(*lg);
+  const Bc bc = make_bc(lbc);
+  const int n = 2 * g.C;
+  if (mode) LBM_KLAUNCH(k_kbc_pressure_rows<1>, dim3((n + 255) / 256), dim3(256), 0, st, pn, in, g, bc, m, m0, m1);
+  else LBM_KLAUNCH(k_kbc_pressure_rows<0>, dim3((n + 255) / 256), dim3(256), 0, st, pn, in, g, bc, m, m0, m1);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
 static int check_kbc(const char* fn, const lbm_kbc_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->s2 > 0.0 && prm->s2 <= 2.0, "%s: s2=%g outside (0, 2]", fn, prm->s2);
@@ -76,7 +150,26 @@ int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
                     const lbm_kbc_params* prm, double* rho, double* u, lbm_stream_t s) {
   int rc = check_kbc("lbm_kbc_collide", prm);
   if (rc) return rc;
+  LBM_REQUIRE(!(bc && bc->pressure_rows), "lbm_kbc_collide: pressure rows need the moments of the source rows: use lbm_kbc_collide_first");
   return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcModel{prm->s2}, rho, u, as_stream(s));
+}
+
+int lbm_kbc_collide_first(double* p, const double* f, const double* m0, const double* m1,
+                          const lbm_geom* g, const lbm_bc* bc, const lbm_kbc_params* prm,
+                          lbm_stream_t s) {
+  int rc = check_kbc("lbm_kbc_collide_first", prm);
+  if (rc) return rc;
+  rc = validate_geom_bc("lbm_kbc_collide_first", g, bc);
+  if (rc) return rc;
+  LBM_REQUIRE(p && f && m0 && m1 && p != f, "lbm_kbc_collide_first: bad argument");
+  LBM_REQUIRE(g->ghost == 0, "lbm_kbc_collide_first: single block only");
+  const long n = (long)g->R * g->C;
+  LBM_KLAUNCH(k_kbc_collide_first, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), p, f,
+              make_geom(*g), m0, m1, KbcModel{prm->s2});
+  LBM_CHECK_LAUNCH();
+  if (bc && bc->pressure_rows)
+    return launch_kbc_pressure_rows(0, p, f, g, bc, KbcModel{prm->s2}, m0, m1, as_stream(s));
+  return LBM_OK;
 }
 
 int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
@@ -84,8 +177,14 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            int row_end, double* rho, double* u, lbm_stream_t s) {
   int rc = check_kbc("lbm_kbc_stream_collide", prm);
   if (rc) return rc;
-  return launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcModel{prm->s2},
-                               row_begin, row_end, rho, u, as_stream(s));
+  rc = launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcModel{prm->s2},
+                             row_begin, row_end, rho, u, as_stream(s));
+  if (rc) return rc;
+  if (bc && bc->pressure_rows) {
+    LBM_REQUIRE(row_begin == 0 && row_end == g->R, "lbm_kbc_stream_collide: pressure rows need the whole block");
+    return launch_kbc_pressure_rows(1, p_new, p_old, g, bc, KbcModel{prm->s2}, nullptr, nullptr, as_stream(s));
+  }
+  return LBM_OK;
 }
 
 }  // extern "C"

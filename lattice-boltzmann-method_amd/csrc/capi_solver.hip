@@ -27,6 +27,7 @@ struct lbm_solver {
   long steps;
   lbm_ibm* ibm;  // optional immersed boundary (not owned)
   double guo_a, guo_b;
+  bool given_moments = false;  // first iteration collides on sv->rho / sv->u as set by the caller
   hipStream_t side = nullptr;  // forcing chain of the immersed boundary, beside the lattice update
   hipEvent_t ev_roi = nullptr, ev_ibm = nullptr;
 };
@@ -38,6 +39,10 @@ static int solver_collide_first(lbm_solver* sv, double* rho, double* u) {
   const double* src = sv->lat[sv->cur];
   if (sv->model == LBM_MODEL_BGK)
     return lbm_bgk_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, rho, u, sv->st);
+  if (sv->given_moments) {  // the driver's held m0 / m1 (ulbm_poiseuille.cpp:85-86); rho, u stay as given
+    sv->given_moments = false;
+    return lbm_kbc_collide_first(dst, src, sv->rho, sv->u, &sv->g, &sv->bc, &sv->kbc, sv->st);
+  }
   return lbm_kbc_collide(dst, src, &sv->g, &sv->bc, &sv->kbc, rho, u, sv->st);
 }
 // with_ibm_overlap: the moments are wanted for the immersed boundary alone -> the ROI rows go first
@@ -88,6 +93,7 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
   sv->st = as_stream(s);
   sv->cur = 0;
   sv->post = false;
+  sv->given_moments = false;
   sv->have_moments = false;
   sv->steps = 0;
   sv->ibm = nullptr;
@@ -126,12 +132,27 @@ int lbm_solver_destroy(lbm_solver* sv) {
   return LBM_OK;
 }
 
+int lbm_solver_set_moments_aos(lbm_solver* sv, const double* rho_host, const double* u_host) {
+  LBM_REQUIRE(sv && rho_host && u_host, "lbm_solver_set_moments_aos: NULL argument");
+  LBM_REQUIRE(sv->model == LBM_MODEL_KBC && !sv->post,
+              "lbm_solver_set_moments_aos: KBC solvers only, after set_f and before the first step");
+  const size_t n = (size_t)sv->g.R * sv->g.C;
+  LBM_CHECK_HIP(hipMemcpyAsync(sv->rho, rho_host, n * sizeof(double), hipMemcpyHostToDevice, sv->st));
+  LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, u_host, 2 * n * sizeof(double), hipMemcpyHostToDevice, sv->st));
+  int rc = lbm_aos_to_soa(sv->u, sv->stage, sv->g.R, sv->g.C, 2, sv->st);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+  sv->given_moments = true;
+  return LBM_OK;
+}
+
 int lbm_solver_set_f_soa_dev(lbm_solver* sv, const double* f_dev) {
   LBM_REQUIRE(sv && f_dev, "lbm_solver_set_f_soa_dev: NULL argument");
   const size_t plane_bytes = (size_t)sv->g.R * sv->g.C * sizeof(double);
   LBM_CHECK_HIP(hipMemcpy2DAsync(sv->lat[sv->cur], (size_t)sv->g.plane_stride * sizeof(double), f_dev,
                                  plane_bytes, plane_bytes, 9, hipMemcpyDeviceToDevice, sv->st));
   sv->post = false;
+  sv->given_moments = false;
   sv->have_moments = false;
   return LBM_OK;
 }
@@ -144,6 +165,7 @@ int lbm_solver_set_f_aos(lbm_solver* sv, const double* f_host) {
   if (rc) return rc;
   LBM_CHECK_HIP(hipStreamSynchronize(sv->st));  // f_host may be reused by the caller
   sv->post = false;
+  sv->given_moments = false;
   sv->have_moments = false;
   return LBM_OK;
 }

@@ -142,12 +142,21 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
     double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
     const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
     double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end) {
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle) {
 #pragma clang fp contract(fast)
   constexpr int NT = TR * TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
   __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
   const int tiles_c = (g.C + TC - 1) / TC;
-  const int r_base = row_begin + (blockIdx.x / tiles_c) * TR, c_base = (blockIdx.x % tiles_c) * TC;
+  // XCD-aware tile order: the hardware deals consecutive workgroups round-robin over the 8 XCDs,
+  // each with its own L2.  Neighbouring tiles share their +-3 ring (and, at 128-B lines, whole
+  // cache lines on both sides of a 32-column tile: 2x read amplification when every XCD fetches
+  // them on its own), so XCD k gets the k-th contiguous eighth of the tile sequence.
+  int tile = blockIdx.x;
+  if (xcd_swizzle) {
+    const int per = gridDim.x / 8;
+    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+  }
+  const int r_base = row_begin + (tile / tiles_c) * TR, c_base = (tile % tiles_c) * TC;
   const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
   const int tr = threadIdx.x / TC, tc = threadIdx.x % TC;
   const int r = r_base + tr, c = c_base + tc;

@@ -125,6 +125,10 @@ class Solver {  // single-phase BGK / KBC block, wraps lbm_solver
   }
   void set_f(const std::vector<double>& f_aos) { check(lbm_solver_set_f_aos(h_, f_aos.data())); }
   void set_f(const Field& f_soa) { check(lbm_solver_set_f_soa_dev(h_, f_soa.data())); }
+  // KBC: the moments the driver HOLDS for its first collide (test/ulbm_poiseuille.cpp:85-86)
+  void set_moments(const std::vector<double>& rho, const std::vector<double>& u) {
+    check(lbm_solver_set_moments_aos(h_, rho.data(), u.data()));
+  }
   std::vector<double> get_f() {
     std::vector<double> f((size_t)R_ * C_ * 9);
     check(lbm_solver_get_f_aos(h_, f.data()));

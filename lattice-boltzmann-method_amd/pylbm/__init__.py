@@ -119,7 +119,7 @@ class Lib:
         return int(self.raw.lbm_default_plane_pad(R, C))
 
     def reset_tuning(self):
-        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile"):
+        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd"):
             self.set_tuning(k, -1)
 
 
@@ -170,6 +170,13 @@ class Solver:
         f = np.ascontiguousarray(f, dtype=np.float64)
         assert f.shape == (self.R, self.C, 9)
         self.lib.solver_set_f_aos(self.h, _hptr(f))
+
+    def set_moments(self, rho, u):
+        """KBC: the first iteration collides on these held moments (ulbm_poiseuille.cpp:85-86)"""
+        rho = np.ascontiguousarray(rho, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert rho.shape == (self.R, self.C) and u.shape == (self.R, self.C, 2)
+        self.lib.solver_set_moments_aos(self.h, _hptr(rho), _hptr(u))
 
     def get_f(self):
         f = np.empty((self.R, self.C, 9))

@@ -566,6 +566,55 @@ void orc_kbc_steps(double* f, double* m0, double* m1, int R, int C, double s2, i
   }
 }
 
+// test/ulbm_poiseuille.cpp:104-141 loop body, nsteps times, from the driver's start state if
+// init != 0 (adve_f = 0 from the ctor, m0 = 1 (:86), m1 = 0): kbc.collide(); pressure-periodic rows
+// with solver::incomp_equilibrium for the imposed density and kbc.iequi_f.pow(-1) as f_equi
+// (:36-58, :122); advect; halfway bounce-back columns (:126-132); m0 = sum f, m1 = f c^T / m0.
+void orc_upo_steps(double* f, double* m0, double* m1, int H, int W, double s2, double rho_inlet,
+                   double rho_outlet, int init, int nsteps) {
+  const size_t N = (size_t)H * W;
+  small_grid_guard sg(N);
+  if (init) {
+    std::fill(f, f + N * 9, 0.0);
+    std::fill(m0, m0 + N, 1.0);
+    std::fill(m1, m1 + N * 2, 0.0);
+  }
+  std::vector<double> coll(N * 9);
+  for (int t = 0; t < nsteps; ++t) {
+    orc_kbc_collide(coll.data(), f, m0, m1, s2, H, W, nullptr);  // :121
+    // periodic_boundary_condition(kbc.coll_f, kbc.iequi_f.pow(-1), kbc.m1, kbc.m0, ...) :122
+    // (reads rows 1 and H-2 of coll, writes rows 0 and H-1: no overlap for H >= 4)
+    for (int e = 0; e < 2; ++e) {
+      const int dst = e ? H - 1 : 0, src = e ? 1 : H - 2;
+      const double rho_bc = (e ? rho_outlet : rho_inlet) * 1.0;  // rho_inlet * temp_rho (ones)
+      for (int c = 0; c < W; ++c) {
+        const size_t i = nid(src, c, W);
+        const double ux = m1[2 * i], uy = m1[2 * i + 1];
+        double te[9], pe[9];
+        node_feq_incomp(te, rho_bc, ux, uy);                 // :50 / :54
+        kbc_feq_poly(pe, ux, uy, ux * ux, uy * uy);          // eval_iequilibrium, ulbm.cpp:230-246
+        for (int q = 0; q < 9; ++q) {
+          const double iequi = 1.0 / (pe[q] * m0[i]);        // what collide() stored
+          const double fequi = 1.0 / iequi;                  // .pow(-1)
+          coll[nid(dst, c, W) * 9 + q] = (te[q] + coll[i * 9 + q]) - fequi;  // :51 / :55
+        }
+      }
+    }
+    advect(f, coll.data(), H, W);  // :123
+    for (int r = 0; r < H; ++r) {  // :126-132
+      const size_t a = nid(r, W - 1, W) * 9, b = nid(r, 0, W) * 9;
+      f[a + 4] = coll[a + 2];
+      f[a + 7] = coll[a + 5];
+      f[a + 8] = coll[a + 6];
+      f[b + 2] = coll[b + 4];
+      f[b + 5] = coll[b + 7];
+      f[b + 6] = coll[b + 8];
+    }
+    orc_calc_rho(m0, f, H, W);      // :136
+    orc_calc_u(m1, f, m0, H, W);    // :138
+  }
+}
+
 void orc_kbc_shear_init(double* m0, double* m1, int R, int C, double u_max, double alpha,
                         double delta) {
   // ulbm_double_shear_flow.cpp:42-63 ("R" used for both dimensions, 6.2832 for 2*pi)

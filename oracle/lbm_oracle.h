@@ -67,6 +67,11 @@ void orc_kbc_collide(double* coll, const double* f, const double* m0, const doub
                      double s2, int R, int C, double* gamma_out);
 /* collide, advect, moment update (ulbm_double_shear_flow.cpp:119-142). */
 void orc_kbc_steps(double* f, double* m0, double* m1, int R, int C, double s2, int nsteps);
+/* test/ulbm_poiseuille.cpp:104-141 loop body, nsteps times (KBC + pressure-periodic rows with the
+ * incompressible equilibrium + halfway bounce-back columns); init != 0: start from the driver's
+ * state (adve_f = 0, m0 = 1, m1 = 0). */
+void orc_upo_steps(double* f, double* m0, double* m1, int H, int W, double s2, double rho_inlet,
+                   double rho_outlet, int init, int nsteps);
 /* shear-layer IC, ulbm_double_shear_flow.cpp:42-63 */
 void orc_kbc_shear_init(double* m0, double* m1, int R, int C, double u_max,
                         double alpha, double delta);

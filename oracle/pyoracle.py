@@ -188,6 +188,16 @@ class Oracle:
         self.lib.orc_kbc_steps(_p(f), _p(m0), _p(m1), R, C, ct.c_double(s2), int(nsteps))
         return f, m0, m1
 
+    def upo_steps(self, H, W, s2, rho_inlet, rho_outlet, nsteps, state=None):
+        """test/ulbm_poiseuille.cpp loop; state = (f, m0, m1) to continue, None = the driver's start"""
+        if state is None:
+            f, m0, m1 = np.zeros((H, W, 9)), np.ones((H, W)), np.zeros((H, W, 2))
+        else:
+            f, m0, m1 = (_c(a).copy() for a in state)
+        self.lib.orc_upo_steps(_p(f), _p(m0), _p(m1), H, W, ct.c_double(s2), ct.c_double(rho_inlet),
+                               ct.c_double(rho_outlet), int(state is None), int(nsteps))
+        return f, m0, m1
+
     def kbc_shear_init(self, R, C, u_max=0.02, alpha=80.0, delta=0.05):
         m0 = np.empty((R, C)); m1 = np.empty((R, C, 2))
         self.lib.orc_kbc_shear_init(_p(m0), _p(m1), R, C, ct.c_double(u_max), ct.c_double(alpha),
@@ -325,6 +335,15 @@ class Ref:
         self.lib.ref_kbc_steps(_p(f), _p(m0), _p(m1), R, C, ct.c_double(s2),
                                int(init_from_moments), int(nsteps), _p(coll))
         return (f, m0, m1, coll) if want_coll else (f, m0, m1)
+
+    def upo_steps(self, H, W, s2, rho_inlet, rho_outlet, nsteps, state=None):
+        if state is None:
+            f, m0, m1 = np.zeros((H, W, 9)), np.ones((H, W)), np.zeros((H, W, 2))
+        else:
+            f, m0, m1 = (_c(a).copy() for a in state)
+        self.lib.ref_upo_steps(_p(f), _p(m0), _p(m1), H, W, ct.c_double(s2), ct.c_double(rho_inlet),
+                               ct.c_double(rho_outlet), int(state is None), int(nsteps))
+        return f, m0, m1
 
     def diff_x(self, psi):
         psi = _c(psi); R, C = psi.shape

@@ -141,6 +141,51 @@ void ref_kbc_steps(double* f, double* m0, double* m1, int R, int C, double s2,
   unwrap(m1, k.m1);
 }
 
+// The loop body of test/ulbm_poiseuille.cpp:104-141 driven through the reference's own
+// ulbm::d2q9::kbc and solver::incomp_equilibrium (this harness only sequences the calls the way
+// that main does; the unmodified main itself is oracle/_ref/upo, 300000 steps).
+void ref_upo_steps(double* f, double* m0, double* m1, int H, int W, double s2, double rho_inlet,
+                   double rho_outlet, int init, int nsteps) {
+  using torch::indexing::Ellipsis;
+  using torch::indexing::Slice;
+  set_f64_default();
+  ulbm::d2q9::kbc k{H, W, s2};
+  if (init) {
+    k.m0.fill_(1.0);
+  } else {
+    k.adve_f = wrap(f, {H, W, 9});
+    k.m0 = wrap(m0, {H, W});
+    k.m1 = wrap(m1, {H, W, 2});
+  }
+  const Tensor c = solver::c;
+  for (int t = 0; t < nsteps; ++t) {
+    k.collide();
+    {
+      Tensor f_equi = k.iequi_f.pow(-1);
+      Tensor temp_equi = torch::zeros({1, W, 9});
+      Tensor temp_rho = torch::ones({1, W, 1});
+      solver::incomp_equilibrium(temp_equi, k.m1.index({-2, Ellipsis}).unsqueeze(0), rho_inlet * temp_rho);
+      k.coll_f.index({0, Ellipsis}) =
+          (temp_equi + k.coll_f.index({-2, Ellipsis}) - f_equi.index({-2, Ellipsis})).squeeze(0).clone().detach();
+      solver::incomp_equilibrium(temp_equi, k.m1.index({1, Ellipsis}).unsqueeze(0), rho_outlet * temp_rho);
+      k.coll_f.index({-1, Ellipsis}) =
+          (temp_equi + k.coll_f.index({1, Ellipsis}) - f_equi.index({1, Ellipsis})).squeeze(0).clone().detach();
+    }
+    k.advect();
+    k.adve_f.index({Slice(), -1, 4}) = k.coll_f.index({Slice(), -1, 2}).clone().detach();
+    k.adve_f.index({Slice(), -1, 7}) = k.coll_f.index({Slice(), -1, 5}).clone().detach();
+    k.adve_f.index({Slice(), -1, 8}) = k.coll_f.index({Slice(), -1, 6}).clone().detach();
+    k.adve_f.index({Slice(), 0, 2}) = k.coll_f.index({Slice(), 0, 4}).clone().detach();
+    k.adve_f.index({Slice(), 0, 5}) = k.coll_f.index({Slice(), 0, 7}).clone().detach();
+    k.adve_f.index({Slice(), 0, 6}) = k.coll_f.index({Slice(), 0, 8}).clone().detach();
+    k.m0 = k.adve_f.sum(-1).detach().clone();
+    k.m1 = (torch::matmul(k.adve_f, c.transpose(0, 1)) / k.m0.unsqueeze(-1)).detach().clone();
+  }
+  unwrap(f, k.adve_f);
+  unwrap(m0, k.m0);
+  unwrap(m1, k.m1);
+}
+
 // ---- differential (src/differential.cpp:23-33) -----------------------------------
 void ref_diff_x(double* out, const double* psi, int R, int C) {
   set_f64_default();

@@ -83,10 +83,13 @@ def bench_cg(R, C, n=20):
     del f_r, f_b
     tiles = os.environ.get("LBM_CG_TILES", "1").split(",")
     for tile in tiles:
-        lib.set_tuning(b"cg_fused", 1)
-        lib.set_tuning(b"cg_tile", int(tile))
-        dt = timed(lambda k: sv.step(k), n, warm=3)
-        report("colour-gradient MRT (fused, one launch per step, tile %s)" % tile, R, C, dt, 288)
+        for xcd in os.environ.get("LBM_CG_XCD", "1").split(","):
+            lib.set_tuning(b"cg_fused", 1)
+            lib.set_tuning(b"cg_tile", int(tile))
+            lib.set_tuning(b"cg_xcd", int(xcd))
+            dt = timed(lambda k: sv.step(k), n, warm=3)
+            report("colour-gradient MRT (fused, one launch per step, tile %s, xcd order %s)" % (tile, xcd), R, C, dt, 288)
+    lib.set_tuning(b"cg_xcd", -1)
     lib.set_tuning(b"cg_fused", 0)
     dt = timed(lambda k: sv.step(k), n, warm=3)
     report("colour-gradient MRT (two-pass, reference operation order)", R, C, dt, 496)

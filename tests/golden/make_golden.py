@@ -12,6 +12,10 @@ Sources of each fixture
   dsf_128.npz       test/ulbm_double_shear_flow.cpp      main(), unmodified (oracle/_ref/dsf)
   kbc_units.npz     ulbm::d2q9::kbc collide/advect via ref_capi.cpp
   diff5.npz         differential::x / ::y via ref_capi.cpp
+  upo_units.npz     the loop of test/ulbm_poiseuille.cpp on the reference's own kbc class and
+                    solver::incomp_equilibrium, sequenced by ref_capi.cpp (ref_upo_steps)
+  upo_128.npz       test/ulbm_poiseuille.cpp main(), unmodified (oracle/_ref/upo): 300000 steps, hours
+                    of CPU time -- only with --upo-dir pointing at a finished run's output files
 """
 import argparse
 import os
@@ -151,6 +155,32 @@ def gen_kbc(r, o):
     save("kbc_units.npz", **out)
 
 
+def upo_params(H, W):
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    p_grad = 8.0 * nu * 0.05 / (W * W)
+    return s2, 3.0 * (H - 1) * p_grad + 1.0, 1.0      # ulbm_poiseuille.cpp:70-83
+
+
+def gen_upo_units(r):
+    out = {}
+    for tag, (H, W), steps in (("a", (24, 20), (1, 2, 10, 100)), ("b", (128, 128), (50,))):
+        s2, rin, rout = upo_params(H, W)
+        out[f"{tag}_shape"] = np.array([H, W])
+        for n in steps:
+            f, m0, m1 = r.upo_steps(H, W, s2, rin, rout, n)
+            out[f"{tag}_{n}_f"], out[f"{tag}_{n}_m0"], out[f"{tag}_{n}_m1"] = f, m0, m1
+    save("upo_units.npz", **out)
+
+
+def gen_upo_main(d):
+    """snapshots of the unmodified main (index i <-> state BEFORE iteration 100 i, :109-117)"""
+    idx = np.array([1, 2, 5, 10, 50, 200, 1000, 2999])
+    pre = "ulbm-poiseuillehpt-"            # file_prefix + "hpt-ux.pt" (:151-154)
+    out = {k: np.ascontiguousarray(load_pt(os.path.join(d, f"{pre}{k}.pt"))[..., idx]) for k in ("ux", "uy", "rho")}
+    save("upo_128.npz", snap_index=idx, snapshot_period=np.int64(100), **out)
+
+
 def gen_diff(r):
     rng = np.random.default_rng(3)
     psi = rng.standard_normal((19, 31))
@@ -162,9 +192,16 @@ def gen_diff(r):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-dsf", action="store_true", help="skip the ~minutes-long shear-flow run")
+    ap.add_argument("--upo-dir", default="", help="directory holding the .pt files of a finished oracle/_ref/upo run")
+    ap.add_argument("--only-upo", action="store_true")
     a = ap.parse_args()
     build_ref()
     r, o = Ref(), Oracle()
+    gen_upo_units(r)
+    if a.upo_dir:
+        gen_upo_main(a.upo_dir)
+    if a.only_upo:
+        sys.exit(0)
     gen_solver_units(r, o)
     gen_kbc(r, o)
     gen_diff(r)

@@ -181,3 +181,17 @@ def test_slab_ring_cylinder_driver(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["check"] == "bitwise equal to one block"
     assert line["markers"] == 94 and abs(line["Fs"][0]) > 0
+
+
+def test_ulbm_poiseuille_driver_vs_oracle(tmp_path, oracle):
+    """drivers/ulbm_poiseuille.cpp (KBC + pressure rows + bounce-back columns from the driver's zero
+    start) at the reference's 128 x 128 for 300 iterations: moments as the driver holds them."""
+    run("ulbm_poiseuille", "--T", 300, "--dump", tmp_path / "upo")
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    rin = 3.0 * 127 * (8.0 * nu * 0.05 / (128 * 128)) + 1.0
+    _, m0, m1 = oracle.upo_steps(128, 128, s2, rin, 1.0, 300)
+    u = np.fromfile(tmp_path / "upo-u.f64").reshape(128, 128, 2)
+    rho = np.fromfile(tmp_path / "upo-rho.f64").reshape(128, 128)
+    assert relerr(rho, m0) < 1e-14 and np.abs(u - m1).max() < 1e-15
+    assert u[64, 64, 0] > 0           # the pressure drop drives the flow along +r

@@ -120,3 +120,36 @@ def test_config3_size_equals_tiled_small_box(lib, oracle):
     assert bits_equal(download_aos(lib, first), want)
     assert bool((blocks == first.view(9, 1, 64, 1, 64)).all())
     sv.close()
+
+
+def _upo_case(H, W):
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    rin = 3.0 * (H - 1) * (8.0 * nu * 0.05 / (W * W)) + 1.0        # ulbm_poiseuille.cpp:70-83
+    bc = pylbm.Bc.periodic()
+    bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK                  # :126-132
+    bc.pressure_rows, bc.rho_inlet, bc.rho_outlet = 1, rin, 1.0     # :36-58, :122
+    return s2, rin, bc
+
+
+@pytest.mark.parametrize("H,W", [(24, 20), (128, 128)])
+def test_ulbm_poiseuille_preset_vs_oracle_and_reference(lib, oracle, H, W):
+    """SURVEY 8(f) row 1, test/ulbm_poiseuille.cpp: KBC + pressure-periodic rows (imposed density through
+    solver::incomp_equilibrium, f_equi = iequi_f.pow(-1)) + bounce-back columns, started like the
+    driver from adve_f = 0 with held moments m0 = 1, m1 = 0.  Bitwise vs the oracle; vs the
+    reference's own classes (tests/golden/upo_units.npz) to rounding."""
+    s2, rin, bc = _upo_case(H, W)
+    g = golden("upo_units.npz")
+    tag, steps = ("a", (1, 2, 10, 100)) if (H, W) == (24, 20) else ("b", (50,))
+    sv = pylbm.Solver(lib, pylbm.MODEL_KBC, H, W, pylbm.KbcParams(s2), bc=bc)
+    sv.set_f(np.zeros((H, W, 9)))
+    sv.set_moments(np.ones((H, W)), np.zeros((H, W, 2)))
+    done = 0
+    for n in steps:
+        sv.step(n - done, record_moments=False)
+        done = n
+        got = sv.get_f()
+        want_f, want_m0, want_m1 = oracle.upo_steps(H, W, s2, rin, 1.0, n)
+        assert bits_equal(got, want_f), (n, ulp_diff(got, want_f))
+        assert relerr(got, g[f"{tag}_{n}_f"]) < 1e-12, (n, relerr(got, g[f"{tag}_{n}_f"]))
+    sv.close()

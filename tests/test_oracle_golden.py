@@ -160,3 +160,19 @@ def test_gravity_main(oracle):
     assert full["steps"] == int(g["last_t"]) == 8301           # same early exit as the reference
     assert relerr(full["f"], g["fs"][..., -1]) < 1e-11
     assert relerr(full["u"][..., 0], g["ux"][..., -1]) < 1e-10
+
+
+def test_ulbm_poiseuille_loop_vs_reference_classes(oracle):
+    """orc_upo_steps (test/ulbm_poiseuille.cpp:104-141) against the same loop run on the reference's
+    own ulbm::d2q9::kbc + solver::incomp_equilibrium (fixture upo_units.npz, ref_upo_steps)."""
+    g = golden("upo_units.npz")
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    for tag, steps in (("a", (1, 2, 10, 100)), ("b", (50,))):
+        H, W = (int(v) for v in g[f"{tag}_shape"])
+        rin = 3.0 * (H - 1) * (8.0 * nu * 0.05 / (W * W)) + 1.0
+        for n in steps:
+            f, m0, m1 = oracle.upo_steps(H, W, s2, rin, 1.0, n)
+            assert relerr(f, g[f"{tag}_{n}_f"]) < 1e-12, (tag, n)
+            assert relerr(m0, g[f"{tag}_{n}_m0"]) < 1e-12, (tag, n)
+            assert np.abs(m1 - g[f"{tag}_{n}_m1"]).max() < 1e-12, (tag, n)
