@@ -195,6 +195,11 @@ int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
 int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g,
                            const lbm_bc* bc, const lbm_kbc_params* prm, int row_begin,
                            int row_end, double* rho, double* u, lbm_stream_t s);
+/* n_steps = 2..4 time steps per launch (register sliding window, as lbm_bgk_stream_collide_xn) with the
+ * reassociated KBC collision; periodic / halo edges only */
+int lbm_kbc_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_kbc_params* prm, int n_steps,
+                              int row_begin, int row_end, lbm_stream_t s);
 /* First iteration of a driver that HOLDS its moments (test/ulbm_poiseuille.cpp:85-86 starts from
  * adve_f = 0 with m0 = 1, m1 = 0): kbc::collide() on the given (m0 [R][C], m1 [2][R][C]) instead of
  * the populations' own moments, single block.  With bc->pressure_rows the KBC flavour of the

@@ -111,6 +111,41 @@ static int launch_kbc_pressure_rows(int mode, double* pn, const double* in, cons
   return LBM_OK;
 }
 
+// launch_stream_collide_sw restricted to the instantiations KBC needs (2 waves per block so that
+// the register allocator is not capped: the collision keeps ~100 doubles live next to the ring)
+static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double* po,
+                                        const lbm_geom* lg, const lbm_bc* lbc, const KbcFastModel& m,
+                                        int depth, int row_begin, int row_end, hipStream_t st) {
+  int rc = validate_geom_bc(fn, lg, lbc);
+  if (rc) return rc;
+  LBM_REQUIRE(pn && po && pn != po, "%s: NULL or aliased lattices", fn);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R,
+              "%s: row range [%d, %d) outside [0, %d)", fn, row_begin, row_end, lg->R);
+  const Bc bc = make_bc(lbc);
+  LBM_REQUIRE(!bc_needs_edge_pass(bc) && !bc.pressure_rows,
+              "%s: multi-step launches support periodic / halo edges only", fn);
+  LBM_REQUIRE(lg->ghost == 0 || lg->ghost >= depth, "%s: ghost=%d rows, need 0 or >= %d", fn, lg->ghost, depth);
+  LBM_REQUIRE(lg->R >= 4 * depth + 8 && lg->C >= 64, "%s: lattice %dx%d too small for %d-step launches", fn, lg->R, lg->C, depth);
+  if (row_begin == row_end) return LBM_OK;
+  const Geom g = make_geom(*lg);
+  const int nrows = row_end - row_begin;
+  int rpc = tuning("sw_rows", 64);
+  if (rpc > nrows) rpc = nrows;
+  const int W = 64 - 2 * (depth - 1);
+  const int strips = (g.C + W - 1) / W, chunks = (nrows + rpc - 1) / rpc;
+  const long n_waves_l = (long)strips * chunks;
+  LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
+  const int n_waves = (int)n_waves_l;
+  const dim3 grid((n_waves + 1) / 2);
+  switch (depth) {
+    case 2: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); break;
+    case 3: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); break;
+    default: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 4, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); break;
+  }
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
 static int check_kbc(const char* fn, const lbm_kbc_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->s2 > 0.0 && prm->s2 <= 2.0, "%s: s2=%g outside (0, 2]", fn, prm->s2);
@@ -151,6 +186,8 @@ int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
   int rc = check_kbc("lbm_kbc_collide", prm);
   if (rc) return rc;
   LBM_REQUIRE(!(bc && bc->pressure_rows), "lbm_kbc_collide: pressure rows need the moments of the source rows: use lbm_kbc_collide_first");
+  if (tuning("kbc_fast", 1))
+    return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcFastModel{prm->s2}, rho, u, as_stream(s));
   return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcModel{prm->s2}, rho, u, as_stream(s));
 }
 
@@ -177,6 +214,12 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            int row_end, double* rho, double* u, lbm_stream_t s) {
   int rc = check_kbc("lbm_kbc_stream_collide", prm);
   if (rc) return rc;
+  // the reassociated collision (kbc.hpp) unless the caller asks for the reference operation order
+  // (tuning "kbc_fast" = 0) or the pressure rows -- which re-collide their source rows in that order
+  // -- are in use
+  if (tuning("kbc_fast", 1) && !(bc && bc->pressure_rows))
+    return launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcFastModel{prm->s2},
+                                 row_begin, row_end, rho, u, as_stream(s));
   rc = launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcModel{prm->s2},
                              row_begin, row_end, rho, u, as_stream(s));
   if (rc) return rc;
@@ -185,6 +228,21 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
     return launch_kbc_pressure_rows(1, p_new, p_old, g, bc, KbcModel{prm->s2}, nullptr, nullptr, as_stream(s));
   }
   return LBM_OK;
+}
+
+// n_steps = 2..4 time steps in ONE launch through the register sliding window of the BGK path
+// (d2q9.hpp k_stream_collide_sw, here with the reassociated KBC collision): periodic / halo
+// edges only, whole block or a row range of a slab with ghost >= n_steps.  The reference-order
+// model (tuning "kbc_fast" = 0) has no multi-step instantiation: callers fall back to single steps.
+int lbm_kbc_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_kbc_params* prm, int n_steps,
+                              int row_begin, int row_end, lbm_stream_t s) {
+  int rc = check_kbc("lbm_kbc_stream_collide_xn", prm);
+  if (rc) return rc;
+  LBM_REQUIRE(tuning("kbc_fast", 1), "lbm_kbc_stream_collide_xn: multi-step launches exist for the reassociated collision only (kbc_fast = 1)");
+  LBM_REQUIRE(n_steps >= 2 && n_steps <= 4, "lbm_kbc_stream_collide_xn: %d steps per launch (supported: 2..4)", n_steps);
+  return launch_stream_collide_sw_kbc("lbm_kbc_stream_collide_xn", p_new, p_old, g, bc,
+                                      KbcFastModel{prm->s2}, n_steps, row_begin, row_end, as_stream(s));
 }
 
 }  // extern "C"

@@ -208,13 +208,14 @@ int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host) {
 static bool solver_can_fuse_steps(const lbm_solver* sv) {
   const lbm_bc& b = sv->bc;
   auto plain = [](int m) { return m == LBM_EDGE_PERIODIC; };
-  return sv->model == LBM_MODEL_BGK && !sv->ibm && !b.pressure_rows && plain(b.row_lo) &&
-         plain(b.row_hi) && plain(b.col_lo) && plain(b.col_hi) && sv->g.C >= 64;
+  const bool model_ok = sv->model == LBM_MODEL_BGK || (sv->model == LBM_MODEL_KBC && tuning("kbc_fast", 1));
+  return model_ok && !sv->ibm && !b.pressure_rows && plain(b.row_lo) && plain(b.row_hi) &&
+         plain(b.col_lo) && plain(b.col_hi) && sv->g.C >= 64;
 }
 
 int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
   LBM_REQUIRE(sv && n >= 0, "lbm_solver_step: bad argument (n=%d)", n);
-  const int max_depth = tuning("solver_depth", 5);
+  const int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 3) : tuning("solver_depth", 5);
   for (int i = 0; i < n;) {
     // temporal blocking: D driver iterations in one launch (bit-identical); the iteration that
     // must record moments, and the first one on a pre-collision state, run singly
@@ -222,9 +223,13 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
     int depth = fusable < max_depth ? fusable : max_depth;
     while (depth >= 2 && sv->g.R < 4 * depth + 8) --depth;
     if (sv->post && depth >= 2 && solver_can_fuse_steps(sv)) {
-      int rc = lbm_bgk_stream_collide_xn(sv->lat[sv->cur ^ 1], sv->lat[sv->cur], &sv->g, &sv->bc,
-                                         &sv->bgk, depth, 0, sv->g.R, sv->st);
+      int rc = sv->model == LBM_MODEL_KBC
+                   ? lbm_kbc_stream_collide_xn(sv->lat[sv->cur ^ 1], sv->lat[sv->cur], &sv->g, &sv->bc,
+                                               &sv->kbc, depth > 4 ? 4 : depth, 0, sv->g.R, sv->st)
+                   : lbm_bgk_stream_collide_xn(sv->lat[sv->cur ^ 1], sv->lat[sv->cur], &sv->g, &sv->bc,
+                                               &sv->bgk, depth, 0, sv->g.R, sv->st);
       if (rc) return rc;
+      if (sv->model == LBM_MODEL_KBC && depth > 4) depth = 4;
       sv->cur ^= 1;
       sv->steps += depth;
       i += depth;

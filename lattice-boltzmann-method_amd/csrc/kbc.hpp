@@ -125,4 +125,112 @@ struct KbcModel {
   }
 };
 
+// The same collision, reassociated ("fast" path, default of the stream+collide entry points; the
+// model above follows the reference operation by operation and is bit-identical to the oracle).
+// Same mathematics as kbc::collide() with the populations' own moments:
+//  * central moments through the raw moments (butterfly over opposite pairs) and the binomial
+//    shift, instead of nine 9-term sums of products of (c - u) powers;
+//  * eval_delta_s / eval_delta_h (ulbm.cpp:157-228) are, term by term,
+//        delta_s = M^-1 N^-1 (0,0,0, C3, C4, C5, 0,0,0) - feq
+//        delta_h = M^-1 N^-1 (0,...,0, C6, C7, C8)      - feq  (+ the "ux2 + uy" slip of rows 5-8, Q8)
+//    so both come from ONE back-transform each and the product-form equilibrium
+//    feq_q = rho psi_cx(ux) psi_cy(uy);  the relaxed populations reuse the same two vectors:
+//        f' = f - s2 (S - cs2 rho G) - gamma s2 (H - cs4 rho V8);
+//  * the conserved central moments T0, T1, T2 (zero up to rounding when the moments are the
+//    populations' own) are not carried through the back-transform;
+//  * 1 / feq_q = (1/rho)(1/psi_cx)(1/psi_cy): 7 reciprocals (v_rcp_f64 + one Newton step) and one
+//    division instead of 12 IEEE divisions.  FMA contraction is on.
+// ~330 f64 operations per node instead of ~940; agreement with the reference-order model to
+// rounding (tests/test_gpu_kbc.py states the tolerance).
+struct KbcFastModel {
+  double s2;
+
+  __device__ __forceinline__ static double rcp(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+  }
+
+  __device__ __forceinline__ void collide(double (&f)[Q], double& rho, double& ux, double& uy) const {
+    // contract(on): products feeding a sum IN THE SAME EXPRESSION become FMAs, decided by the front
+    // end -- identical in every kernel this model is inlined into (single-step, sliding-window,
+    // edge pass), which contract(fast) (back-end, context dependent) does not guarantee
+#pragma clang fp contract(on)
+    constexpr double cs2 = 1.0 / 3.0, cs4 = 1.0 / 9.0;
+    // raw moments (butterfly)
+    const double a = f[1] + f[3], b = f[2] + f[4], d57 = f[5] + f[7], d68 = f[6] + f[8];
+    const double e57 = f[5] - f[7], e68 = f[6] - f[8];
+    const double m22 = d57 + d68, m11 = d57 - d68, m21 = e57 + e68, m12 = e57 - e68;
+    const double m20 = a + m22, m02 = b + m22;
+    rho = (f[0] + a) + (b + m22);
+    const double jx = (f[1] - f[3]) + m12, jy = (f[2] - f[4]) + m21;
+    const double irho = rcp(rho);
+    ux = jx * irho;
+    uy = jy * irho;
+    const double ux2 = ux * ux, uy2 = uy * uy, uxy = ux * uy;
+    // central moments (binomial shift)
+    const double k20 = m20 - jx * ux, k02 = m02 - jy * uy, C5 = m11 - jx * uy;
+    const double C6 = (m21 - uy * m20) - 2.0 * ux * C5;
+    const double C7 = (m12 - ux * m02) - 2.0 * uy * C5;
+    const double C8 = ((m22 - 2.0 * (uy * m21 + ux * m12)) + (uy2 * m20 + ux2 * m02)) +
+                      (4.0 * uxy * m11 - 3.0 * (jx * ux) * uy2);
+    // S = M^-1 N^-1 (0,0,0,C3,C4,C5,0,0,0), C3 = k20 + k02, C4 = k20 - k02
+    const double i6s = k20 * uy + 2.0 * C5 * ux, i7s = k02 * ux + 2.0 * C5 * uy;
+    const double i8s = (k02 * ux2 + k20 * uy2) + 4.0 * C5 * uxy;
+    double S[Q], H[Q];
+    S[0] = i8s - (k20 + k02);
+    S[1] = 0.5 * (k20 - (i7s + i8s));
+    S[3] = 0.5 * (k20 + (i7s - i8s));
+    S[2] = 0.5 * (k02 - (i6s + i8s));
+    S[4] = 0.5 * (k02 + (i6s - i8s));
+    S[5] = 0.25 * ((C5 + i8s) + (i6s + i7s));
+    S[6] = 0.25 * ((i8s - C5) + (i6s - i7s));
+    S[7] = 0.25 * ((C5 + i8s) - (i6s + i7s));
+    S[8] = 0.25 * ((i8s - C5) - (i6s - i7s));
+    // H = M^-1 N^-1 (0,...,0,C6,C7,C8)
+    const double i8h = 2.0 * (C6 * uy + C7 * ux) + C8;
+    H[0] = i8h;
+    H[1] = -0.5 * (C7 + i8h);
+    H[3] = 0.5 * (C7 - i8h);
+    H[2] = -0.5 * (C6 + i8h);
+    H[4] = 0.5 * (C6 - i8h);
+    H[5] = 0.25 * (i8h + (C6 + C7));
+    H[6] = 0.25 * (i8h + (C6 - C7));
+    H[7] = 0.25 * (i8h - (C6 + C7));
+    H[8] = 0.25 * (i8h - (C6 - C7));
+    // product-form equilibrium and its reciprocal
+    const double px0 = (1.0 - cs2) - ux2, pxp = 0.5 * ((ux2 + cs2) + ux), pxm = 0.5 * ((ux2 + cs2) - ux);
+    const double py0 = (1.0 - cs2) - uy2, pyp = 0.5 * ((uy2 + cs2) + uy), pym = 0.5 * ((uy2 + cs2) - uy);
+    const double rx0 = rho * px0, rxp = rho * pxp, rxm = rho * pxm;       // rho folded into the x factor
+    const double ix0 = irho * rcp(px0), ixp = irho * rcp(pxp), ixm = irho * rcp(pxm);
+    const double iy0 = rcp(py0), iyp = rcp(pyp), iym = rcp(pym);
+    const double fe[Q] = {rx0 * py0, rxp * py0, rx0 * pyp, rxm * py0, rx0 * pym,
+                          rxp * pyp, rxm * pyp, rxm * pym, rxp * pym};
+    const double ie[Q] = {ix0 * iy0, ixp * iy0, ix0 * iyp, ixm * iy0, ix0 * iym,
+                          ixp * iyp, ixm * iyp, ixm * iym, ixp * iym};
+    // delta_h rows 5-8 as written in the reference: "ux2 + uy" where the algebra has ux2 * uy (Q8)
+    const double qa = -0.25 * rho * ((ux2 + uy) - ux2 * uy), qb = -0.25 * rho * ((uy - ux2) + ux2 * uy);
+    const double quirk[Q] = {0.0, 0.0, 0.0, 0.0, 0.0, qa, qa, qb, qb};
+    double num = 0.0, den = 0.0;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const double ds = S[q] - fe[q], dh = (H[q] - fe[q]) + quirk[q];
+      const double t = dh * ie[q];
+      num += ds * t;
+      den += dh * t;
+    }
+    const double is2 = 1.0 / s2;
+    const double gamma = is2 - (1.0 - is2) * (num / den);  // eval_gamma :138-148
+    // relaxed populations: f - s2 (S - cs2 rho G) - gamma s2 (H - cs4 rho V8)
+    const double g2 = ux2 + uy2, cr = cs2 * rho, gs = gamma * s2, hr = cs4 * rho;
+    const double G[Q] = {g2 - 2.0,
+                         -0.5 * ((g2 - 1.0) + ux), -0.5 * ((g2 - 1.0) + uy),
+                         -0.5 * ((g2 - 1.0) - ux), -0.5 * ((g2 - 1.0) - uy),
+                         0.25 * (g2 + (ux + uy)), 0.25 * (g2 - (ux - uy)),
+                         0.25 * (g2 - (ux + uy)), 0.25 * (g2 + (ux - uy))};
+    constexpr double V8[Q] = {1.0, -0.5, -0.5, -0.5, -0.5, 0.25, 0.25, 0.25, 0.25};
+#pragma unroll
+    for (int q = 0; q < Q; ++q) f[q] = (f[q] - s2 * (S[q] - cr * G[q])) - gs * (H[q] - hr * V8[q]);
+  }
+};
+
 }  // namespace lbm

@@ -126,7 +126,15 @@ if __name__ == "__main__":
     if "bgk" in which:
         bench_single(pylbm.MODEL_BGK, "BGK (solver context)", 8192, 8192, pylbm.BgkParams(1.2, 0))
     if "kbc" in which:
-        bench_single(pylbm.MODEL_KBC, "KBC", 4096, 4096, pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+        for depth in os.environ.get("LBM_KBC_DEPTH", "3").split(","):
+            lib.set_tuning(b"kbc_depth", int(depth))
+            bench_single(pylbm.MODEL_KBC, "KBC (reassociated collision, %s step(s) per launch)" % depth, 4096, 4096,
+                         pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+        lib.set_tuning(b"kbc_depth", -1)
+        lib.set_tuning(b"kbc_fast", 0)
+        bench_single(pylbm.MODEL_KBC, "KBC (reference operation order)", 4096, 4096,
+                     pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+        lib.set_tuning(b"kbc_fast", -1)
     if "cg" in which:
         bench_cg(8192, 2048)
     if "ibm" in which:
