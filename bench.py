@@ -208,7 +208,8 @@ def main():
         kern_ms = dev_ms / launches                      # avg duration of one launch
         alg_bytes = R * C * BYTES_PER_LUP * steps_per_launch   # algorithmic bytes one launch stands for
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        kernel = (f"k_stream_collide_sw<BgkModel,{a.xn},4,nt>" if use_xn else
+        fast = dict(kv.split("=") for kv in a.tune).get("bgk_fast", "1") != "0"   # library default: 1
+        kernel = ((f"k_stream_collide_sw<BgkFastModel,{a.xn},2,nt>" if fast else f"k_stream_collide_sw<BgkModel,{a.xn},4,nt>") if use_xn else
                   f"k_stream_collide_tb2<BgkModel,{a.tb_rows},512,nt>" if use_x2
                   else "k_stream_collide_v3<BgkModel,256,1,nt,nt>")
         # HBM bytes per launch cannot be read live (PMC counters need rocprofv3); report the figure

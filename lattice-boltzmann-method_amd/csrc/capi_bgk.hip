@@ -56,6 +56,16 @@ static int launch_pressure_rows(bool from_post, double* pn, const double* in, co
   return LBM_OK;
 }
 
+// The reassociated collision (d2q9.hpp BgkFastModel) serves the plain compressible model on every
+// launch path -- first collide, single step, multi-step -- so that results do not depend on how a
+// run is cut into launches.  tuning "bgk_fast" = 0 selects the reference operation order
+// (bit-identical to the oracle); lattices with pressure rows keep it throughout (those rows
+// re-collide their source rows in that order).
+static bool use_fast_bgk(const lbm_bgk_params* prm, const lbm_bc* bc) {
+  return !prm->force_mode && !prm->incompressible && !prm->delta_form && !(bc && bc->pressure_rows) &&
+         tuning("bgk_fast", 1);
+}
+
 static int check_bgk(const char* fn, const lbm_bgk_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->omega > 0.0 && prm->omega < 2.0, "%s: omega=%g outside (0, 2)", fn, prm->omega);
@@ -73,6 +83,8 @@ int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
                     const lbm_bgk_params* prm, double* rho, double* u, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_collide", prm);
   if (rc) return rc;
+  if (use_fast_bgk(prm, bc))
+    return launch_collide_only("lbm_bgk_collide", p, f, g, bc, BgkFastModel{prm->omega}, rho, u, as_stream(s));
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   rc = launch_collide_only("lbm_bgk_collide", p, f, g, bc, m, rho, u, as_stream(s));
   if (rc) return rc;
@@ -89,6 +101,9 @@ int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            int row_end, double* rho, double* u, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_stream_collide", prm);
   if (rc) return rc;
+  if (use_fast_bgk(prm, bc))
+    return launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, BgkFastModel{prm->omega},
+                                 row_begin, row_end, rho, u, as_stream(s));
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   rc = launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, m, row_begin, row_end,
                              rho, u, as_stream(s));
@@ -106,6 +121,9 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
                               int row_end, lbm_stream_t s) {
   int rc = check_bgk("lbm_bgk_stream_collide_x2", prm);
   if (rc) return rc;
+  if (use_fast_bgk(prm, bc))
+    return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, BgkFastModel{prm->omega},
+                                    row_begin, row_end, as_stream(s));
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, m, row_begin,
                                   row_end, as_stream(s));
@@ -119,6 +137,8 @@ int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom
   const char* fn = "lbm_bgk_stream_collide_xn";
   if (!prm->force_mode) {  // compile-time model: no mode branches inside the unrolled window
     const int key = (prm->incompressible ? 2 : 0) | (prm->delta_form ? 1 : 0);
+    if (use_fast_bgk(prm, bc))  // leaner collision: best at one 2-wave block per SIMD pair (146.6 k vs 137 k MLUPS)
+      return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkFastModel{prm->omega}, n_steps, row_begin, row_end, as_stream(s), 2);
     switch (key) {
       case 0: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
       case 1: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));

@@ -157,7 +157,7 @@ int launch_stream_collide_x2(const char* fn, double* pn, const double* po, const
 template <class Model>
 int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const lbm_geom* lg,
                              const lbm_bc* lbc, const Model& m, int depth, int row_begin,
-                             int row_end, hipStream_t st) {
+                             int row_end, hipStream_t st, int default_waves = 4) {
   int rc = validate_geom_bc(fn, lg, lbc);
   if (rc) return rc;
   LBM_REQUIRE(pn && po && pn != po, "%s: NULL or aliased lattices", fn);
@@ -178,7 +178,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   const int strips = (g.C + W - 1) / W, chunks = (nrows + rpc - 1) / rpc;
   const long n_waves_l = (long)strips * chunks;
   LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
-  const int n_waves = (int)n_waves_l, nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", 4);
+  const int n_waves = (int)n_waves_l, nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
