@@ -409,13 +409,19 @@ int lbm_snapshot_host(lbm_snapshot* sn, const double** rho, const double** u, lo
 int lbm_solver_checkpoint_save(lbm_solver* sv, const char* path);
 int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
 
-/* Tuning table for lbm_*_stream_collide's interior path (benchmarks / tests; every setting
- * produces bit-identical results).  Keys: "variant" (0 generic, 1 one node/thread grid-stride,
+/* Tuning table.  Launch-shape keys (every setting produces identical results) and the three
+ * implementation switches, which select between a model's two collision implementations:
+ *   "bgk_fast", "kbc_fast", "cg_fused" (default 1): the reassociated collision / the one-launch
+ *   two-phase step; 0 = the reference's operation order, bit-identical to the CPU oracle.
+ * Further keys: "kbc_depth" (steps lbm_solver_step fuses per launch for KBC, default 3), "cg_tile"
+ * (0: 8x32, 1: 16x32 [default], 2: 8x64), "cg_xcd" (XCD-contiguous tile order, default 1).
+ * Launch-shape keys: "variant" (0 generic, 1 one node/thread grid-stride,
  * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0
  * non-temporal loads, bit 1 non-temporal stores; default 3), "block" (128..1024, default 256),
  * "rows" (rows per thread 1/2/4, default 1), "grid_cap" (variants 1-2); two-step LDS kernel:
  * "tb_rows" (tile height, default 8), "tb_block" (default 512), "tb_order"; sliding-window kernel:
- * "sw_rows" (rows per wavefront chunk, default 64), "sw_waves" (waves per workgroup, default 4);
+ * "sw_rows" (rows per wavefront chunk, default 64), "sw_waves" (waves per workgroup, default 4; 2 for
+ * the reassociated BGK model);
  * "solver_depth" (steps lbm_solver_step fuses per launch on periodic BGK blocks, default 5, 1 =
  * off).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);
