@@ -414,7 +414,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  *   "bgk_fast", "kbc_fast", "cg_fused" (default 1): the reassociated collision / the one-launch
  *   two-phase step; 0 = the reference's operation order, bit-identical to the CPU oracle.
  * Further keys: "kbc_depth" (steps lbm_solver_step fuses per launch for KBC, default 3), "cg_tile"
- * (0: 8x32, 1: 16x32 [default], 2: 8x64), "cg_xcd" (XCD-contiguous tile order, default 1).
+ * (0: 8x32, 1: 16x32 [default], 2: 8x64), "cg_xcd" (XCD-contiguous tile order, default 0).
  * Launch-shape keys: "variant" (0 generic, 1 one node/thread grid-stride,
  * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0
  * non-temporal loads, bit 1 non-temporal stores; default 3), "block" (128..1024, default 256),
