@@ -391,6 +391,28 @@ int lbm_ring_bgk_step_ibm(lbm_ring* rg, double* dst, const double* src, const lb
                           const lbm_bgk_params* prm, int edge_rows, lbm_ibm* ib, double guo_a,
                           double guo_b, double* rho, double* u, lbm_stream_t main);
 
+/* ---- population links between lattices on one GPU (multi-block topologies) -----------------------
+ * The reference glues blocks by slice assignments after advect (test/decompose_domain.cpp:181-187;
+ * test/decompose_domain_loop.cpp:235-261, plus its slice-assignment walls :173-231): here a table of
+ * element links built once, applied in ONE gather launch per step,
+ *     dst[dst_lattice][q_dst][r0 + k dr][c0 + k dc] = src[src_lattice][q_src][sr0 + k sdr][sc0 + k sdc],
+ * k = 0 .. count-1.  Slices are added in the order the driver executes them; where two write the
+ * same destination element the later one wins (resolved on the host, the device pass is race-free).
+ * dst / src of lbm_links_apply: one pointer per lattice (typically f_adve and f_coll of each block). */
+typedef struct lbm_links lbm_links;
+int lbm_links_create(lbm_links** out, int n_lattices /* <= 8 */, const lbm_geom* geoms);
+int lbm_links_add(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, int dr, int dc, int src_lat,
+                  int q_src, int sr0, int sc0, int sdr, int sdc, int count);
+int lbm_links_finalize(lbm_links* t);
+int lbm_links_count(const lbm_links* t); /* distinct destination elements */
+int lbm_links_apply(lbm_links* t, double* const* dst, const double* const* src, lbm_stream_t s);
+int lbm_links_destroy(lbm_links* t);
+/* uniform momentum source on rows [row_begin, row_end) of a post-collision lattice
+ * (decompose_domain_loop.cpp:152-160): p_q += ((1 - omega/2)((a + b u.c_q)(F.c_q) - a u.F)) w_q with the
+ * step's u [2][R][C]; (a, b) = (3, 9) in that driver */
+int lbm_bgk_add_force_rows(double* p, const lbm_geom* g, const double* u, double omega, double Fr,
+                           double Fc, double a, double b, int row_begin, int row_end, lbm_stream_t s);
+
 /* ---- snapshots and checkpoints (the reference only torch::save()s snapshot
  * stacks at the end of a run, e.g. horizontal_poiseuille_test.cpp:157-160) ------------------------ */
 typedef struct lbm_snapshot lbm_snapshot;
@@ -415,6 +437,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  *   two-phase step; 0 = the reference's operation order, bit-identical to the CPU oracle.
  * Further keys: "kbc_depth" (steps lbm_solver_step fuses per launch for KBC, default 3), "cg_tile"
  * (0: 8x32, 1: 16x32 [default], 2: 8x64), "cg_xcd" (XCD-contiguous tile order, default 0).
+ * The environment variable LBM_TUNE="key=value,key=value" pre-loads the table (compiled drivers).
  * Launch-shape keys: "variant" (0 generic, 1 one node/thread grid-stride,
  * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0
  * non-temporal loads, bit 1 non-temporal stores; default 3), "block" (128..1024, default 256),

@@ -1,6 +1,7 @@
 // C ABI, part 1: status, device memory/stream/event helpers, layout converters and the
 // seven unfused solver:: operators (parity surface, not the hot path).
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -22,8 +23,29 @@ void set_error(const char* fmt, ...) {
 static std::mutex g_tune_mu;
 static std::map<std::string, int> g_tune;
 
+// environment LBM_TUNE="key=value,key=value": initial entries of the table (compiled drivers have
+// no other way to reach lbm_set_tuning without a rebuild); lbm_set_tuning overrides them
+static void tuning_from_env() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* e = std::getenv("LBM_TUNE");
+  if (!e) return;
+  std::string s(e);
+  size_t pos = 0;
+  while (pos < s.size()) {
+    size_t end = s.find(',', pos);
+    if (end == std::string::npos) end = s.size();
+    const std::string kv = s.substr(pos, end - pos);
+    const size_t eq = kv.find('=');
+    if (eq != std::string::npos && eq > 0) g_tune.emplace(kv.substr(0, eq), std::atoi(kv.c_str() + eq + 1));
+    pos = end + 1;
+  }
+}
+
 int tuning(const char* key, int dflt) {
   std::lock_guard<std::mutex> lk(g_tune_mu);
+  tuning_from_env();
   auto it = g_tune.find(key);
   return it == g_tune.end() ? dflt : it->second;
 }

@@ -76,7 +76,10 @@ struct small_grid_guard {
   explicit small_grid_guard(size_t nodes) {
 #ifdef _OPENMP
     old = omp_get_max_threads();
-    if (nodes < 16384) omp_set_num_threads(1);
+    // one thread per 8192 nodes at most: on a 128-thread host the fork/join of a full team costs
+    // more than a whole pass over a 128 x 128 block
+    const int want = (int)(nodes / 8192);
+    if (want < old) omp_set_num_threads(want < 1 ? 1 : want);
 #else
     (void)nodes; old = 1;
 #endif
@@ -426,6 +429,145 @@ void orc_ddm_run(int H, int W, int T, double omega, double rho_inlet, double rho
     for (int c = 0; c < W; ++c) fB[nid(0, c, W) * 9 + 1] = cA[nid(H - 1, c, W) * 9 + 1];
     for (int c = 1; c < W; ++c) fB[nid(0, c, W) * 9 + 5] = cA[nid(H - 1, c - 1, W) * 9 + 5];
     for (int c = 0; c < W - 1; ++c) fB[nid(0, c, W) * 9 + 8] = cA[nid(H - 1, c + 1, W) * 9 + 8];
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// test/decompose_domain_loop.cpp: four blocks A (L x L/4), B (L/4 x L/2), C (L x L/4),
+// D (L/4 x L/2) closed into a square loop channel by column-seam bindings; momentum source in A
+// ---------------------------------------------------------------------------------
+namespace {
+struct Blk {
+  int R, C;
+  double *f, *coll;  // adve_f, coll_f  [R][C][9]
+};
+// dst.f[r0 .. r1, col, q] = src.coll[s0 .., scol, sq]; negative indices count from the end
+// (the torch slices of :192-261 written out; `none` = an open slice end)
+const int none = 1 << 30;
+inline int norm(int i, int n) { return i == none ? n : (i < 0 ? i + n : i); }
+void bind_rows(const Blk& d, int r0, int r1, int col, int q, const Blk& s, int s0, int scol, int sq) {
+  r0 = norm(r0, d.R);
+  r1 = norm(r1, d.R);
+  s0 = norm(s0, s.R);
+  col = norm(col, d.C);
+  scol = norm(scol, s.C);
+  for (int k = 0; k < r1 - r0; ++k)
+    d.f[nid(r0 + k, col, d.C) * 9 + q] = s.coll[nid(s0 + k, scol, s.C) * 9 + sq];
+}
+void wall_rows(const Blk& b) {  // top :192-195 / bottom :196-199 of every block
+  for (int c = 0; c < b.C; ++c) {
+    const size_t t = nid(0, c, b.C) * 9, m = nid(b.R - 1, c, b.C) * 9;
+    b.f[t + 8] = b.coll[t + 6];
+    b.f[t + 1] = b.coll[t + 3];
+    b.f[t + 5] = b.coll[t + 7];
+    b.f[m + 7] = b.coll[m + 5];
+    b.f[m + 3] = b.coll[m + 1];
+    b.f[m + 6] = b.coll[m + 8];
+  }
+}
+void wall_col(const Blk& b, int r0, int r1, bool left) {  // :200-207, :224-231
+  r0 = norm(r0, b.R);
+  r1 = norm(r1, b.R);
+  const int col = left ? 0 : b.C - 1;
+  for (int r = r0; r < r1; ++r) {
+    const size_t i = nid(r, col, b.C) * 9;
+    if (left) {
+      b.f[i + 2] = b.coll[i + 4];
+      b.f[i + 5] = b.coll[i + 7];
+      b.f[i + 6] = b.coll[i + 8];
+    } else {
+      b.f[i + 4] = b.coll[i + 2];
+      b.f[i + 7] = b.coll[i + 5];
+      b.f[i + 8] = b.coll[i + 6];
+    }
+  }
+}
+}  // namespace
+
+// nsteps iterations of :112-262 from the driver's start state (m_0 = 1, m_1 = 0, adve_f = feq).
+// Outputs: adve_f of the four blocks and rho / u as computed in the LAST iteration (what the
+// snapshot taken at t = nsteps stores, before the driver adds F to A's u on the force rows, :114).
+void orc_ddl_run(int L, int nsteps, double omega, double Fr, double* fA, double* fB, double* fC,
+                 double* fD, double* rho[4], double* u[4]) {
+  const int L2 = L / 2, L4 = L / 4;
+  small_grid_guard sg((size_t)L * L4);
+  const int Rs[4] = {L, L4, L, L4}, Cs[4] = {L4, L2, L4, L2};
+  double* fs[4] = {fA, fB, fC, fD};
+  std::vector<double> coll[4], feq[4];
+  Blk b[4];
+  for (int k = 0; k < 4; ++k) {
+    const size_t N = (size_t)Rs[k] * Cs[k];
+    coll[k].resize(N * 9);
+    feq[k].resize(N * 9);
+    b[k] = Blk{Rs[k], Cs[k], fs[k], coll[k].data()};
+    for (size_t i = 0; i < N; ++i) {  // :77-80
+      rho[k][i] = 1.0;
+      u[k][2 * i] = u[k][2 * i + 1] = 0.0;
+    }
+    orc_equilibrium(fs[k], u[k], rho[k], Rs[k], Cs[k]);  // :105-108
+  }
+  const Blk &A = b[0], &B = b[1], &C = b[2], &D = b[3];
+  const int f0 = L4 + 5, f1 = L4 + 55;  // force_idx :63
+  for (int t = 0; t < nsteps; ++t) {
+    for (int k = 0; k < 4; ++k) {  // :134-150
+      orc_calc_rho(rho[k], fs[k], Rs[k], Cs[k]);
+      orc_calc_u(u[k], fs[k], rho[k], Rs[k], Cs[k]);
+      orc_equilibrium(feq[k].data(), u[k], rho[k], Rs[k], Cs[k]);
+    }
+    // A: adve + (-omega (adve - equi)), then + S on the force rows (:152-160); S with (3, 9)
+    {
+      const size_t N = (size_t)A.R * A.C;
+#pragma omp parallel for schedule(static)
+      for (long i = 0; i < (long)(N * 9); ++i) A.coll[i] = A.f[i] + (-omega * (A.f[i] - feq[0][i]));
+      for (int r = f0; r < f1; ++r)
+        for (int c = 0; c < A.C; ++c) {
+          const size_t i = nid(r, c, A.C);
+          const double ux = u[0][2 * i], uy = u[0][2 * i + 1];
+          const double uF = ux * Fr + uy * 0.0;
+          for (int q = 0; q < 9; ++q) {
+            const double uc = ux * CX[q] + uy * CY[q];
+            const double Fc = Fr * CX[q] + 0.0 * CY[q];
+            const double S = ((1 - 0.5 * omega) * ((3.0 + 9.0 * uc) * Fc - 3.0 * uF)) * W9[q];
+            A.coll[i * 9 + q] = A.coll[i * 9 + q] + S;
+          }
+        }
+    }
+    for (int k = 1; k < 4; ++k) orc_collision(coll[k].data(), fs[k], feq[k].data(), omega, Rs[k], Cs[k]);  // :161-163
+    for (int k = 0; k < 4; ++k) advect(fs[k], coll[k].data(), Rs[k], Cs[k]);                               // :166-169
+    // no-slip walls :173-231 (in the driver's order: later assignments win at shared corners)
+    wall_rows(A);
+    wall_col(A, L4, -L4, true);
+    wall_col(A, 1, -1, false);
+    wall_rows(B);
+    wall_rows(C);
+    wall_col(C, 1, -1, true);
+    wall_col(C, L4, -L4, false);
+    wall_rows(D);
+    // bindings :235-261
+    bind_rows(A, -L4, -1, 0, 6, B, 1, -1, 6);
+    bind_rows(A, -L4, none, 0, 2, B, 0, -1, 2);
+    bind_rows(A, -L4 + 1, none, 0, 5, B, 0, -1, 5);
+    bind_rows(B, 1, none, -1, 8, A, -L4, 0, 8);
+    bind_rows(B, 0, none, -1, 4, A, -L4, 0, 4);
+    bind_rows(B, 0, -1, -1, 7, A, -L4 + 1, 0, 7);
+    bind_rows(B, 0, -1, 0, 6, C, -L4 + 1, -1, 6);
+    bind_rows(B, 0, none, 0, 2, C, -L4, -1, 2);
+    bind_rows(B, 1, none, 0, 5, C, -L4, -1, 5);
+    bind_rows(C, -L4, -1, -1, 7, B, 1, 0, 7);
+    bind_rows(C, -L4, none, -1, 4, B, 0, 0, 4);
+    bind_rows(C, -L4 + 1, none, -1, 8, B, 0, 0, 8);
+    bind_rows(C, 0, L4 - 1, -1, 7, D, 1, 0, 7);
+    bind_rows(C, 0, L4, -1, 4, D, 0, 0, 4);
+    bind_rows(C, 1, L4, -1, 8, D, 0, 0, 8);
+    bind_rows(D, 0, -1, 0, 6, C, 1, -1, 6);
+    bind_rows(D, 0, none, 0, 2, C, 0, -1, 2);
+    bind_rows(D, 1, none, 0, 5, C, 0, -1, 5);
+    bind_rows(D, 0, -1, -1, 7, A, 1, 0, 7);
+    bind_rows(D, 0, none, -1, 4, A, 0, 0, 4);
+    bind_rows(D, 1, none, -1, 8, A, 0, 0, 8);
+    bind_rows(A, 0, L4 - 1, 0, 6, D, 1, -1, 6);
+    bind_rows(A, 0, L4, 0, 2, D, 0, -1, 2);
+    bind_rows(A, 1, L4, 0, 5, D, 0, -1, 5);
   }
 }
 

@@ -58,6 +58,14 @@ int orc_gravity_run(int H, int W, int T, double omega, double Fr, double Fc, dou
 void orc_ddm_run(int H, int W, int T, double omega, double rho_inlet, double rho_outlet,
                  double* fA, double* fB, double* uA, double* uB, double* rhoA, double* rhoB);
 
+/* ---- test/decompose_domain_loop.cpp: four blocks A (L x L/4), B (L/4 x L/2), C, D closed into a loop
+ * channel by column-seam bindings with row offsets (:235-261), no-slip walls (:173-231), momentum
+ * source F = (Fr, 0) with the (3, 9) coefficients on rows [L/4+5, L/4+55) of A (:63,:152-160).
+ * nsteps iterations from the driver's start state; rho[k] / u[k] = moments computed in the last
+ * iteration (k = 0..3 for A..D). */
+void orc_ddl_run(int L, int nsteps, double omega, double Fr, double* fA, double* fB, double* fC,
+                 double* fD, double* rho[4], double* u[4]);
+
 /* ---- ulbm::d2q9::kbc (src/ulbm.cpp:91-320) ---- */
 /* feq from (m0, ux, uy) with the caller-supplied ux2/uy2 (the ctor leaves them 0
  * for the driver's initialisation, ulbm_double_shear_flow.cpp:96). */

@@ -188,6 +188,19 @@ class Oracle:
         self.lib.orc_kbc_steps(_p(f), _p(m0), _p(m1), R, C, ct.c_double(s2), int(nsteps))
         return f, m0, m1
 
+    def ddl_run(self, L, nsteps, omega=None, Fr=3e-3):
+        """test/decompose_domain_loop.cpp: returns {"f": [A..D], "rho": [...], "u": [...]}"""
+        if omega is None:
+            omega = 1.0 / (np.sqrt(3.0 / 16.0) + 0.5)
+        shapes = [(L, L // 4), (L // 4, L // 2), (L, L // 4), (L // 4, L // 2)]
+        f = [np.empty(s + (9,)) for s in shapes]
+        rho = [np.empty(s) for s in shapes]
+        u = [np.empty(s + (2,)) for s in shapes]
+        P4 = ct.POINTER(ct.c_double) * 4
+        self.lib.orc_ddl_run(int(L), int(nsteps), ct.c_double(omega), ct.c_double(Fr), *[_p(a) for a in f],
+                             P4(*[_p(a) for a in rho]), P4(*[_p(a) for a in u]))
+        return dict(f=f, rho=rho, u=u)
+
     def upo_steps(self, H, W, s2, rho_inlet, rho_outlet, nsteps, state=None):
         """test/ulbm_poiseuille.cpp loop; state = (f, m0, m1) to continue, None = the driver's start"""
         if state is None:

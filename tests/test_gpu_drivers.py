@@ -195,3 +195,34 @@ def test_ulbm_poiseuille_driver_vs_oracle(tmp_path, oracle):
     rho = np.fromfile(tmp_path / "upo-rho.f64").reshape(128, 128)
     assert relerr(rho, m0) < 1e-14 and np.abs(u - m1).max() < 1e-15
     assert u[64, 64, 0] > 0           # the pressure drop drives the flow along +r
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_decompose_domain_loop_driver_vs_oracle(tmp_path, oracle, fast):
+    """SURVEY 8(f) row 4, test/decompose_domain_loop.cpp: four blocks closed into a loop channel by
+    column-seam bindings, walls as slice assignments, momentum source on a row window of A --
+    drivers/decompose_domain_loop.cpp on lbm_links_* (one gather launch for the ~70 slice assignments
+    of a step).  L = 128, 300 steps: bitwise vs the oracle in the reference operation order; 1e-12
+    with the default reassociated collision (blocks B, C, D; A's delta form always runs in order)."""
+    env = dict(os.environ)
+    exe = os.path.join(BIN, "decompose_domain_loop")
+    assert os.path.exists(exe)
+    # the tuning switch is process-wide state of the library: hand it over through the environment
+    env["LBM_TUNE"] = f"bgk_fast={fast}"
+    r = subprocess.run([exe, "--L", "128", "--T", "300", "--dump", str(tmp_path / "ddl")], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    want = oracle.ddl_run(128, 300)
+    shapes = [(128, 32), (32, 64), (128, 32), (32, 64)]
+    for k, name in enumerate("ABCD"):
+        R, C = shapes[k]
+        f = np.fromfile(tmp_path / f"ddl-{name}-f.f64").reshape(R, C, 9)
+        rho = np.fromfile(tmp_path / f"ddl-{name}-rho.f64").reshape(R, C)
+        u = np.fromfile(tmp_path / f"ddl-{name}-u.f64").reshape(R, C, 2)
+        if fast:
+            assert relerr(f, want["f"][k]) < 1e-12 and relerr(rho, want["rho"][k]) < 1e-12
+            assert np.abs(u - want["u"][k]).max() < 1e-13
+        else:
+            assert np.array_equal(f, want["f"][k]), name
+            assert np.array_equal(rho, want["rho"][k]) and np.array_equal(u, want["u"][k]), name
+    assert want["u"][0][32 + 30, 16, 0] > 1e-3      # the source drives the flow along +r in A
