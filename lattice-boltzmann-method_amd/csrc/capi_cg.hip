@@ -89,6 +89,23 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   return LBM_OK;
 }
 
+template <int WAVES>
+static int launch_cg_strip_t(double* pn_r, double* pn_b, const double* in_r, const double* in_b,
+                             const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
+                             double* rho_b, double* u, double* psi, double* snu, const MacroIdx& mi,
+                             int row_begin, int row_end, hipStream_t st) {
+  int rpc = tuning("cg_rows", 64);
+  const int nrows = row_end - row_begin;
+  if (rpc > nrows) rpc = nrows;
+  const int strips = (g.C + CG_SW - 1) / CG_SW, chunks = (nrows + rpc - 1) / rpc;
+  const int n_waves = strips * chunks;
+  const dim3 grid((n_waves + WAVES - 1) / WAVES);
+  if (psi) LBM_KLAUNCH((k_cg_strip<WAVES, true>), grid, dim3(64 * WAVES), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, rpc, strips, n_waves);
+  else LBM_KLAUNCH((k_cg_strip<WAVES, false>), grid, dim3(64 * WAVES), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, rpc, strips, n_waves);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
 }  // namespace lbm
 
 using namespace lbm;
@@ -179,6 +196,12 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
   const CgFast cf = make_cg_fast(make_cg_consts(*prm));
   const MacroIdx mi = make_macro_idx(gg);
   hipStream_t st = as_stream(s);
+  switch (tuning("cg_strip", 0)) {  // column-strip sliding window (opt-in: slower as written, cg_fused.hpp), waves per workgroup
+    case 0: break;
+    case 2: return launch_cg_strip_t<2>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 4: return launch_cg_strip_t<4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    default: return launch_cg_strip_t<1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+  }
   switch (tuning("cg_tile", 1)) {
     case 0: return launch_cg_fused_t<8, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 2: return launch_cg_fused_t<8, 64, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);

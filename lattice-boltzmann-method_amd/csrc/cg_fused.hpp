@@ -14,7 +14,8 @@
 //    the 496 B/LUP of the two-pass form; halo re-reads hit L2.
 //
 // Results differ from the reference order by rounding only (tolerance stated in
-// tests/test_gpu_cg.py); FMA contraction is enabled here, unlike the rest of the library.
+// tests/test_gpu_cg.py); FMA contraction is enabled here per source expression (contract(on)), so the
+// two kernels below -- tile and column-strip -- produce identical bits.
 #pragma once
 #include "cg.hpp"
 
@@ -75,7 +76,7 @@ template <bool INTERIOR>
 __device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restrict__ in_r,
                                           const double* __restrict__ in_b, const Geom& g,
                                           const Bc& bc, const CgFast& cf, int gr, int gc) {
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
   double fr[Q];
   if (INTERIOR) {
     const long o = g.at(gr, gc);
@@ -110,7 +111,7 @@ __device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restr
 // d/d(row): sum_j [ 2 a0_j (P[4][j] - P[0][j]) + a1_j (P[3][j] - P[1][j]) ]; d/d(col) transposed.
 template <int LDC>
 __device__ __forceinline__ double cg_ddrow(const double (*s)[LDC], int tr, int tc) {
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
   constexpr double k = 1.0 / 5040.0;
   constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
   constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
@@ -124,7 +125,7 @@ __device__ __forceinline__ double cg_ddrow(const double (*s)[LDC], int tr, int t
 }
 template <int LDC>
 __device__ __forceinline__ double cg_ddcol(const double (*s)[LDC], int tr, int tc) {
-#pragma clang fp contract(fast)
+#pragma clang fp contract(on)
   constexpr double k = 1.0 / 5040.0;
   constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
   constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
@@ -137,74 +138,15 @@ __device__ __forceinline__ double cg_ddcol(const double (*s)[LDC], int tr, int t
   return acc;
 }
 
-template <int TR, int TC, int WAVES, bool WITH_FIELDS>
-__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle) {
-#pragma clang fp contract(fast)
-  constexpr int NT = TR * TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
-  __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
-  const int tiles_c = (g.C + TC - 1) / TC;
-  // XCD-aware tile order: the hardware deals consecutive workgroups round-robin over the 8 XCDs,
-  // each with its own L2.  Neighbouring tiles share their +-3 ring (and, at 128-B lines, whole
-  // cache lines on both sides of a 32-column tile: 2x read amplification when every XCD fetches
-  // them on its own), so XCD k gets the k-th contiguous eighth of the tile sequence.
-  int tile = blockIdx.x;
-  if (xcd_swizzle) {
-    const int per = gridDim.x / 8;
-    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
-  }
-  const int r_base = row_begin + (tile / tiles_c) * TR, c_base = (tile % tiles_c) * TC;
-  const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
-  const int tr = threadIdx.x / TC, tc = threadIdx.x % TC;
-  const int r = r_base + tr, c = c_base + tc;
-
-  // own node first (keeps the colour-summed populations in registers), then the +-2 ring.
-  // Replicate padding of the stencils = clamping the node the fields are evaluated at
-  // (differential.cpp:5-9) -- at the edges of the GLOBAL domain only; across a slab seam the
-  // ring continues into the neighbour's (ghost) rows.
-  double ft[Q];
-  CgNode me;
-  constexpr int NH = LR * LC - TR * TC;
-  auto ring_slot = [&](int i, int& lr, int& lc) {
-    if (i < 2 * LC) {
-      lr = i / LC;
-      lc = i % LC;
-    } else if (i < 4 * LC) {
-      lr = TR + 2 + (i - 2 * LC) / LC;
-      lc = (i - 2 * LC) % LC;
-    } else {
-      const int j = i - 4 * LC;
-      lr = 2 + (j >> 2);
-      lc = (j & 3) < 2 ? (j & 3) : TC + (j & 3);
-    }
-  };
-  {
-    me = cg_node<false>(ft, in_r, in_b, g, bc, cf, r > rhi ? rhi : r, c > g.C - 1 ? g.C - 1 : c);
-    for (int i = threadIdx.x; i < NH; i += NT) {
-      int lr, lc;
-      ring_slot(i, lr, lc);
-      int gr = r_base + lr - 2, gc = c_base + lc - 2;
-      gr = gr < rlo ? rlo : (gr > rhi ? rhi : gr);
-      gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
-      double tmp[Q];
-      const CgNode nb = cg_node<false>(tmp, in_r, in_b, g, bc, cf, gr, gc);
-      s_psi[lr][lc] = nb.psi;
-      s_qx[lr][lc] = nb.qx;
-      s_qy[lr][lc] = nb.qy;
-    }
-  }
-  s_psi[tr + 2][tc + 2] = me.psi;
-  s_qx[tr + 2][tc + 2] = me.qx;
-  s_qy[tr + 2][tc + 2] = me.qy;
-  __syncthreads();
-  if (r >= row_end || c >= g.C) return;
-
-  const double gx = cg_ddrow<LDC>(s_psi, tr, tc), gy = cg_ddcol<LDC>(s_psi, tr, tc);
-  const double dxqx = cg_ddrow<LDC>(s_qx, tr, tc), dyqy = cg_ddcol<LDC>(s_qy, tr, tc);
-
+// collision of one node from its colour-summed streamed populations, its macroscopic fields and
+// the four stencil results; writes both colours (and the observable fields on request)
+template <bool WITH_FIELDS>
+__device__ __forceinline__ void cg_collide_store(
+    const double (&ft)[Q], const CgNode& me, double gx, double gy, double dxqx, double dyqy,
+    const CgFast& cf, const Geom& g, const MacroIdx& mi, int r, int c, double* __restrict__ pn_r,
+    double* __restrict__ pn_b, double* __restrict__ rho_r_out, double* __restrict__ rho_b_out,
+    double* __restrict__ u_out, double* __restrict__ psi_out, double* __restrict__ snu_out) {
+#pragma clang fp contract(on)
   const double rr = me.rr, rb = me.rb, ux = me.ux, uy = me.uy, irt = me.irt;
   const double rt = rr + rb;
   const double s_nu = cg_snu_fast(cf, me.psi);
@@ -306,6 +248,201 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
     u_out[mi.n + o] = uy;
     psi_out[oo] = me.psi;
     snu_out[oo] = s_nu;
+  }
+}
+
+template <int TR, int TC, int WAVES, bool WITH_FIELDS>
+__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle) {
+#pragma clang fp contract(on)
+  constexpr int NT = TR * TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
+  __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
+  const int tiles_c = (g.C + TC - 1) / TC;
+  // XCD-aware tile order: the hardware deals consecutive workgroups round-robin over the 8 XCDs,
+  // each with its own L2.  Neighbouring tiles share their +-3 ring (and, at 128-B lines, whole
+  // cache lines on both sides of a 32-column tile: 2x read amplification when every XCD fetches
+  // them on its own), so XCD k gets the k-th contiguous eighth of the tile sequence.
+  int tile = blockIdx.x;
+  if (xcd_swizzle) {
+    const int per = gridDim.x / 8;
+    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+  }
+  const int r_base = row_begin + (tile / tiles_c) * TR, c_base = (tile % tiles_c) * TC;
+  const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
+  const int tr = threadIdx.x / TC, tc = threadIdx.x % TC;
+  const int r = r_base + tr, c = c_base + tc;
+
+  // own node first (keeps the colour-summed populations in registers), then the +-2 ring.
+  // Replicate padding of the stencils = clamping the node the fields are evaluated at
+  // (differential.cpp:5-9) -- at the edges of the GLOBAL domain only; across a slab seam the
+  // ring continues into the neighbour's (ghost) rows.
+  double ft[Q];
+  CgNode me;
+  constexpr int NH = LR * LC - TR * TC;
+  auto ring_slot = [&](int i, int& lr, int& lc) {
+    if (i < 2 * LC) {
+      lr = i / LC;
+      lc = i % LC;
+    } else if (i < 4 * LC) {
+      lr = TR + 2 + (i - 2 * LC) / LC;
+      lc = (i - 2 * LC) % LC;
+    } else {
+      const int j = i - 4 * LC;
+      lr = 2 + (j >> 2);
+      lc = (j & 3) < 2 ? (j & 3) : TC + (j & 3);
+    }
+  };
+  {
+    me = cg_node<false>(ft, in_r, in_b, g, bc, cf, r > rhi ? rhi : r, c > g.C - 1 ? g.C - 1 : c);
+    for (int i = threadIdx.x; i < NH; i += NT) {
+      int lr, lc;
+      ring_slot(i, lr, lc);
+      int gr = r_base + lr - 2, gc = c_base + lc - 2;
+      gr = gr < rlo ? rlo : (gr > rhi ? rhi : gr);
+      gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
+      double tmp[Q];
+      const CgNode nb = cg_node<false>(tmp, in_r, in_b, g, bc, cf, gr, gc);
+      s_psi[lr][lc] = nb.psi;
+      s_qx[lr][lc] = nb.qx;
+      s_qy[lr][lc] = nb.qy;
+    }
+  }
+  s_psi[tr + 2][tc + 2] = me.psi;
+  s_qx[tr + 2][tc + 2] = me.qx;
+  s_qy[tr + 2][tc + 2] = me.qy;
+  __syncthreads();
+  if (r >= row_end || c >= g.C) return;
+
+  const double gx = cg_ddrow<LDC>(s_psi, tr, tc), gy = cg_ddcol<LDC>(s_psi, tr, tc);
+  const double dxqx = cg_ddrow<LDC>(s_qx, tr, tc), dyqy = cg_ddcol<LDC>(s_qy, tr, tc);
+
+  cg_collide_store<WITH_FIELDS>(ft, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out,
+                                rho_b_out, u_out, psi_out, snu_out);
+}
+
+// ---- column-strip sliding window --------------------------------------------------------------
+// One WAVEFRONT owns a strip of 64 columns (60 outputs + the +-2 stencil ring) and walks down a
+// chunk of rows.  Every iteration it (1) streams one new row of both colours and reduces it to
+// psi, Qx, Qy, which go into a wave-private LDS ring of the last 5 rows; (2) collides the row two
+// behind: its own 18 populations are gathered again (L2 / L1 hits: the wave read them two
+// iterations ago) and the 5x5 stencils read the ring.  Rows are wave-uniform, so the gathers are
+// scalar-base + lane-offset loads; nothing is recomputed along r (4 warm-up rows per chunk), only
+// 4 of 64 columns along c; no workgroup barrier exists (LDS visibility inside a wave needs only
+// program order).  Against the tile kernel above: ~2x less HBM read traffic (its +-3 column ring
+// costs whole 128-B lines on both sides of a 32-column tile, 299 B read per node measured).
+// Same per-node arithmetic as the tile kernel: identical bits.
+// MEASURED (8192 x 2048): 6.0-6.4 k MLUPS against the tile kernel's 12.1-12.4 k -- opt-in only
+// (tuning "cg_strip" = 1 / 2 / 4 waves per block).  As written the kernel needs 362 VGPRs (two inlined
+// copies of the gather, each with the boundary path), runs one wave per SIMD without software
+// pipelining, and a 2048-column lattice yields only 35 strips x 128 chunks = 4480 wavefronts;
+// capping it at 256 VGPRs spills (5.2 k).  The BGK sliding window got its speed from prefetching
+// the next row and from 2 waves per SIMD; the same work is open here.
+constexpr int CG_SW = 60;  // output columns per wavefront
+
+template <int WAVES, bool WITH_FIELDS>
+__global__ __launch_bounds__(64 * WAVES) void k_cg_strip(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int rows_per_chunk,
+    int strips, int n_waves) {
+#pragma clang fp contract(on)
+  __shared__ double ring[WAVES][3][5][64 + 4];  // [wave][field][slot][2 pad + lane + 2 pad]
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * WAVES + wib;
+  if (wave >= n_waves) return;
+  const int strip = wave % strips, chunk = wave / strips;
+  const int R0 = row_begin + chunk * rows_per_chunk;
+  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
+  const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
+  const int c = strip * CG_SW - 2 + lane;                   // this lane's column (may be outside)
+  const int cm = c < 0 ? 0 : (c > g.C - 1 ? g.C - 1 : c);   // replicate padding along c
+  const bool lane_out = lane >= 2 && lane < 2 + CG_SW && c < g.C;
+  // strips that touch column 0 / C-1 need the boundary gather (the same-row column copy, Q5)
+  const bool edge_strip = strip * CG_SW - 3 <= 0 || strip * CG_SW + CG_SW + 2 >= g.C - 1;
+  double(*s_psi)[68] = ring[wib][0];
+  double(*s_qx)[68] = ring[wib][1];
+  double(*s_qy)[68] = ring[wib][2];
+
+  auto node = [&](double (&ft)[Q], int row, int col) -> CgNode {
+    // rows 0 / R-1 of the block carry wall fix-ups; (single block) their neighbours wrap
+    const bool plain = !edge_strip && row >= 1 && row <= g.R - 2;
+    if (!plain) return cg_node<false>(ft, in_r, in_b, g, bc, cf, row, col);
+    double fr[Q];
+    const long ro[3] = {g.at(row + 1, 0), g.at(row, 0), g.at(row - 1, 0)};  // source rows of cx = -1, 0, +1
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const long o = q * g.plane + ro[icx(q) + 1] + (col - icy(q));
+      fr[q] = in_r[o];
+      ft[q] = in_b[o];
+    }
+    CgNode n;
+    n.rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
+    n.rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ft[q] += fr[q];
+    const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
+    const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
+    n.irt = 1.0 / (n.rr + n.rb);
+    n.ux = (jx + 0.5 * cf.Gr) * n.irt;
+    n.uy = (jy + 0.5 * cf.Gc) * n.irt;
+    const double a = n.rr * cf.inv_rho0[0], b = n.rb * cf.inv_rho0[1];
+    n.psi = (a - b) / (a + b);
+    const double qcs = cf.qc[0] * n.rr + cf.qc[1] * n.rb;
+    n.qx = qcs * n.ux;
+    n.qy = qcs * n.uy;
+    return n;
+  };
+
+  const int n_iter = (R1 - R0) + 4;
+  for (int i = 0; i < n_iter; ++i) {
+    {  // (1) macroscopic row R0 - 2 + i -> ring slot i % 5
+      int m = R0 - 2 + i;
+      m = m < rlo ? rlo : (m > rhi ? rhi : m);  // replicate padding along r (global edges only)
+      double tmp[Q];
+      const CgNode nb = node(tmp, m, cm);
+      const int slot = i % 5;
+      s_psi[slot][lane + 2] = nb.psi;
+      s_qx[slot][lane + 2] = nb.qx;
+      s_qy[slot][lane + 2] = nb.qy;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i < 4) continue;
+    const int r = R0 + i - 4;  // rows r-2 .. r+2 are in slots (i-4 .. i) % 5
+    if (lane_out) {
+      double ft[Q];
+      const CgNode me = node(ft, r, c);
+      // the 5 ring rows in stencil order; columns lane-2 .. lane+2 sit at [lane .. lane+4]
+      const int s0 = (i - 4) % 5, s1 = (i - 3) % 5, s3 = (i - 1) % 5, s4 = i % 5;
+      constexpr double k = 1.0 / 5040.0;
+      constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
+      constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
+      double gx = 0.0, dxqx = 0.0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {  // == cg_ddrow
+        gx += a0[j] * (s_psi[s4][lane + j] - s_psi[s0][lane + j]);
+        gx += a1[j] * (s_psi[s3][lane + j] - s_psi[s1][lane + j]);
+        dxqx += a0[j] * (s_qx[s4][lane + j] - s_qx[s0][lane + j]);
+        dxqx += a1[j] * (s_qx[s3][lane + j] - s_qx[s1][lane + j]);
+      }
+      double gy = 0.0, dyqy = 0.0;
+#pragma unroll
+      for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
+        const int sl = (i - 4 + ii) % 5;
+        gy += a0[ii] * (s_psi[sl][lane + 4] - s_psi[sl][lane]);
+        gy += a1[ii] * (s_psi[sl][lane + 3] - s_psi[sl][lane + 1]);
+        dyqy += a0[ii] * (s_qy[sl][lane + 4] - s_qy[sl][lane]);
+        dyqy += a1[ii] * (s_qy[sl][lane + 3] - s_qy[sl][lane + 1]);
+      }
+      cg_collide_store<WITH_FIELDS>(ft, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out,
+                                    rho_b_out, u_out, psi_out, snu_out);
+    }
+    // the slot written next iteration is (i + 1) % 5 = the oldest row, no longer read: no hazard
   }
 }
 

@@ -81,6 +81,15 @@ def bench_cg(R, C, n=20):
     sv = pylbm.CgSolver(lib, R, C, prm)
     sv.set_state(np.moveaxis(f_r.cpu().numpy(), 0, -1), np.moveaxis(f_b.cpu().numpy(), 0, -1), rho_r, rho_b, u)
     del f_r, f_b
+    for strip in [x for x in os.environ.get("LBM_CG_STRIP", "").split(",") if x]:
+        for rows in os.environ.get("LBM_CG_ROWS", "64").split(","):
+            lib.set_tuning(b"cg_fused", 1)
+            lib.set_tuning(b"cg_strip", int(strip))
+            lib.set_tuning(b"cg_rows", int(rows))
+            dt = timed(lambda k: sv.step(k), n, warm=3)
+            report("colour-gradient MRT (one launch per step, column strips, %s wave(s)/block, %s rows/chunk)" % (strip, rows), R, C, dt, 288)
+    lib.set_tuning(b"cg_rows", -1)
+    lib.set_tuning(b"cg_strip", 0)
     tiles = os.environ.get("LBM_CG_TILES", "1").split(",")
     for tile in tiles:
         for xcd in os.environ.get("LBM_CG_XCD", "1").split(","):
@@ -94,6 +103,7 @@ def bench_cg(R, C, n=20):
     dt = timed(lambda k: sv.step(k), n, warm=3)
     report("colour-gradient MRT (two-pass, reference operation order)", R, C, dt, 496)
     lib.set_tuning(b"cg_fused", -1)
+    lib.set_tuning(b"cg_strip", -1)
     lib.set_tuning(b"cg_tile", -1)
     sv.close()
 

@@ -280,3 +280,43 @@ def test_cg_fused_two_slabs_equal_single_block(lib, oracle):
         lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc_flat), None)
         got = download_aos(lib, out)
         assert relerr(got, want[key]) < 1e-11, (key, relerr(got, want[key]))
+
+
+@pytest.mark.parametrize("R,C", [(64, 32), (256, 200), (130, 61)])
+def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
+    """The two one-launch kernels -- LDS tile (default) and column-strip sliding window
+    (tuning cg_strip = 1 / 2 / 4) -- share the per-node arithmetic (FMA per source expression): identical
+    bits after 7 steps, including partial strips, partial chunks and the wall / copy edges."""
+    import ctypes as ct
+    from gpu_util import dev, upload_soa
+    from pylbm import _ptr
+    po = pyoracle.cg_params(R, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    flat = pylbm.Geom(R, C, 0)
+    bc = pylbm.Bc()
+    lib.raw.lbm_cg_default_bc(ct.byref(bc))
+    f_r, f_b = upload_soa(lib, s0["f_r"]), upload_soa(lib, s0["f_b"])
+    rr, rb, uu = upload_soa(lib, s0["rho_r"]), upload_soa(lib, s0["rho_b"]), upload_soa(lib, s0["u"])
+    p = [torch.empty((9, R, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+    lib.cg_collide(_ptr(p[0]), _ptr(p[1]), _ptr(f_r), _ptr(f_b), _ptr(rr), _ptr(rb), _ptr(uu),
+                   ct.byref(flat), ct.byref(bc), ct.byref(pg), None, None, None)
+    res = {}
+    try:
+        for strip, rows in ((0, 64), (1, 64), (4, 24), (2, 7)):
+            lib.set_tuning(b"cg_strip", strip)
+            lib.set_tuning(b"cg_rows", rows)
+            a, b = [x.clone() for x in p], [torch.empty_like(p[0]) for _ in range(2)]
+            for _ in range(7):
+                lib.cg_step_fused(_ptr(b[0]), _ptr(b[1]), _ptr(a[0]), _ptr(a[1]), ct.byref(flat), ct.byref(bc),
+                                  ct.byref(pg), 0, R, None, None, None, None, None, None)
+                a, b = b, a
+            torch.cuda.synchronize()
+            res[(strip, rows)] = a
+    finally:
+        lib.set_tuning(b"cg_strip", -1)
+        lib.set_tuning(b"cg_rows", -1)
+    ref = res[(0, 64)]
+    for key, val in res.items():
+        for k in range(2):
+            assert torch.equal(val[k], ref[k]), (key, k, float((val[k] - ref[k]).abs().max()))
