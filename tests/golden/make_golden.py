@@ -14,6 +14,8 @@ Sources of each fixture
   diff5.npz         differential::x / ::y via ref_capi.cpp
   upo_units.npz     the loop of test/ulbm_poiseuille.cpp on the reference's own kbc class and
                     solver::incomp_equilibrium, sequenced by ref_capi.cpp (ref_upo_steps)
+  ddl_512.npz       test/decompose_domain_loop.cpp main(), unmodified (oracle/_ref/ddl): 50000 steps, ~25 min
+                    -- only with --ddl-dir pointing at a finished run's output files
   upo_128.npz       test/ulbm_poiseuille.cpp main(), unmodified (oracle/_ref/upo): 300000 steps, hours
                     of CPU time -- only with --upo-dir pointing at a finished run's output files
 """
@@ -181,6 +183,21 @@ def gen_upo_main(d):
     save("upo_128.npz", snap_index=idx, snapshot_period=np.int64(100), **out)
 
 
+def gen_ddl_main(d):
+    """snapshots of the unmodified test/decompose_domain_loop.cpp main (oracle/_ref/ddl, L = 512,
+    T = 50000, ~25 min): index i <-> state BEFORE iteration 50 i (:112-132), i.e. the moments
+    computed in iteration 50 i - 1, with F already added to A's u on the force rows (:114).
+    Full fields for i = 1, 2, 10; every 4th row / column for i = 100, 999 (size)."""
+    out = dict(full_index=np.array([1, 2, 10]), strided_index=np.array([100, 999]), stride=np.int64(4),
+               snapshot_period=np.int64(50))
+    for blk in "ABCD":
+        for k in ("ux", "uy", "rho"):
+            a = load_pt(os.path.join(d, f"{blk}-domain-decomp-hpt-{k}.pt"))
+            out[f"{blk}_{k}_full"] = np.ascontiguousarray(a[..., [1, 2, 10]])
+            out[f"{blk}_{k}_strided"] = np.ascontiguousarray(a[::4, ::4][..., [100, 999]])
+    save("ddl_512.npz", **out)
+
+
 def gen_diff(r):
     rng = np.random.default_rng(3)
     psi = rng.standard_normal((19, 31))
@@ -194,12 +211,15 @@ if __name__ == "__main__":
     ap.add_argument("--skip-dsf", action="store_true", help="skip the ~minutes-long shear-flow run")
     ap.add_argument("--upo-dir", default="", help="directory holding the .pt files of a finished oracle/_ref/upo run")
     ap.add_argument("--only-upo", action="store_true")
+    ap.add_argument("--ddl-dir", default="", help="directory holding the .pt files of a finished oracle/_ref/ddl run")
     a = ap.parse_args()
     build_ref()
     r, o = Ref(), Oracle()
     gen_upo_units(r)
     if a.upo_dir:
         gen_upo_main(a.upo_dir)
+    if a.ddl_dir:
+        gen_ddl_main(a.ddl_dir)
     if a.only_upo:
         sys.exit(0)
     gen_solver_units(r, o)

@@ -226,3 +226,30 @@ def test_decompose_domain_loop_driver_vs_oracle(tmp_path, oracle, fast):
             assert np.array_equal(f, want["f"][k]), name
             assert np.array_equal(rho, want["rho"][k]) and np.array_equal(u, want["u"][k]), name
     assert want["u"][0][32 + 30, 16, 0] > 1e-3      # the source drives the flow along +r in A
+
+
+def test_decompose_domain_loop_driver_vs_unmodified_main(tmp_path):
+    """drivers/decompose_domain_loop.cpp at the reference's L = 512 against the snapshots of the
+    unmodified main (tests/golden/ddl_512.npz): t = 50 ... 49950 iterations.  Default (reassociated)
+    collision; 1e-12 absolute on u up to 500 iterations, 1e-9 at 5000 / 49950 (stationary state)."""
+    g = golden("ddl_512.npz")
+    L, L4 = 512, 128
+    shapes = dict(A=(512, 128), B=(128, 256), C=(512, 128), D=(128, 256))
+    cases = [("full", j, int(i)) for j, i in enumerate(g["full_index"])] + \
+            [("strided", j, int(i)) for j, i in enumerate(g["strided_index"])]
+    for kind, j, i in cases:
+        T = 50 * i
+        run("decompose_domain_loop", "--L", L, "--T", T, "--dump", tmp_path / "ddl")
+        tol = 1e-12 if T <= 500 else 1e-9
+        for blk, (R, C) in shapes.items():
+            u = np.fromfile(tmp_path / f"ddl-{blk}-u.f64").reshape(R, C, 2)
+            rho = np.fromfile(tmp_path / f"ddl-{blk}-rho.f64").reshape(R, C)
+            ux = u[..., 0].copy()
+            if blk == "A":
+                ux[L4 + 5:L4 + 55] += 3e-3                      # :114, visible in the snapshot only
+            uy = u[..., 1]
+            if kind == "strided":
+                ux, uy, rho = ux[::4, ::4], uy[::4, ::4], rho[::4, ::4]
+            assert np.abs(ux - g[f"{blk}_ux_{kind}"][..., j]).max() < tol, (T, blk)
+            assert np.abs(uy - g[f"{blk}_uy_{kind}"][..., j]).max() < tol, (T, blk)
+            assert np.abs(rho - g[f"{blk}_rho_{kind}"][..., j]).max() < tol, (T, blk)

@@ -176,3 +176,25 @@ def test_ulbm_poiseuille_loop_vs_reference_classes(oracle):
             assert relerr(f, g[f"{tag}_{n}_f"]) < 1e-12, (tag, n)
             assert relerr(m0, g[f"{tag}_{n}_m0"]) < 1e-12, (tag, n)
             assert np.abs(m1 - g[f"{tag}_{n}_m1"]).max() < 1e-12, (tag, n)
+
+
+def _ddl_expect(g, blk, kind, j):
+    return {k: g[f"{blk}_{k}_{kind}"][..., j] for k in ("ux", "uy", "rho")}
+
+
+def test_decompose_domain_loop_vs_unmodified_main(oracle):
+    """orc_ddl_run against the snapshots of the unmodified test/decompose_domain_loop.cpp main
+    (L = 512): snapshot i = moments computed in iteration 50 i - 1, A's u_x on the force rows
+    already carrying the + F of :114."""
+    g = golden("ddl_512.npz")
+    L, L4 = 512, 128
+    for j, i in enumerate(g["full_index"][:2]):
+        got = oracle.ddl_run(L, 50 * int(i))
+        for k, blk in enumerate("ABCD"):
+            want = _ddl_expect(g, blk, "full", j)
+            ux = got["u"][k][..., 0].copy()
+            if blk == "A":
+                ux[L4 + 5:L4 + 55] += 3e-3
+            assert np.abs(ux - want["ux"]).max() < 1e-13, (i, blk)
+            assert np.abs(got["u"][k][..., 1] - want["uy"]).max() < 1e-13, (i, blk)
+            assert relerr(got["rho"][k], want["rho"]) < 1e-14, (i, blk)
