@@ -403,10 +403,26 @@ typedef struct lbm_links lbm_links;
 int lbm_links_create(lbm_links** out, int n_lattices /* <= 8 */, const lbm_geom* geoms);
 int lbm_links_add(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, int dr, int dc, int src_lat,
                   int q_src, int sr0, int sc0, int sdr, int sdc, int count);
+/* affine links: dst = scale * src (+ addends[add0 + k add_stride]; add0 < 0: no addend).  scale = -1
+ * with an addend is the anti-bounce-back "-f_coll + term" of rectangle_sedimentation_test.cpp:152-170;
+ * the addend array is handed to lbm_links_apply_affine (it changes every step there). */
+int lbm_links_add_affine(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, int dr, int dc,
+                         int src_lat, int q_src, int sr0, int sc0, int sdr, int sdc, int count,
+                         double scale, long long add0, long long add_stride);
+int lbm_links_apply_affine(lbm_links* t, double* const* dst, const double* const* src,
+                           const double* addends, lbm_stream_t s);
 int lbm_links_finalize(lbm_links* t);
 int lbm_links_count(const lbm_links* t); /* distinct destination elements */
 int lbm_links_apply(lbm_links* t, double* const* dst, const double* const* src, lbm_stream_t s);
 int lbm_links_destroy(lbm_links* t);
+/* per-row wall terms of rectangle_sedimentation_test.cpp, out[r][9], from the wall velocity
+ * uw = wa u[:, r, col_a] + wb u[:, r, col_b] + shift of the moment field u [2][X][Y]:
+ * mode 0: factor ((2 + 9 (uw.c_q)^2) - 3 uw.uw) w_q                       (anti-bounce-back, :135,:149)
+ * mode 1: factor ((((1 + 3 uw.c_q) + 4.5 (uw.c_q)^2) - 1.5 uw.uw) w_q) field[r]   (concentration inlet, :202) */
+int lbm_wall_terms(double* out, const double* u, int X, int Y, int col_a, double wa, int col_b, double wb,
+                   double shift, int mode, const double* field, double factor, lbm_stream_t s);
+/* out = a * in + b, elementwise (the driver's "u + w_s", :124) */
+int lbm_axpb(double* out, const double* in, double a, double b, long long n, lbm_stream_t s);
 /* uniform momentum source on rows [row_begin, row_end) of a post-collision lattice
  * (decompose_domain_loop.cpp:152-160): p_q += ((1 - omega/2)((a + b u.c_q)(F.c_q) - a u.F)) w_q with the
  * step's u [2][R][C]; (a, b) = (3, 9) in that driver */

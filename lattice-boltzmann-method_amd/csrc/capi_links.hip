@@ -30,6 +30,59 @@ __global__ __launch_bounds__(256) void k_links_apply(LinkPtrs p, int n, const in
   p.dst[l & 15][dst_off[k]] = p.src[(l >> 4) & 15][src_off[k]];
 }
 
+// affine links: dst = scale * src (+ addends[add_idx]); scale = -1 is the anti-bounce-back
+// "-f_coll + term" of rectangle_sedimentation_test.cpp:152-170, 210-230 (exact: -1 * x = -x)
+__global__ __launch_bounds__(256) void k_links_apply_affine(LinkPtrs p, int n, const int* __restrict__ lat,
+                                                            const long* __restrict__ dst_off,
+                                                            const long* __restrict__ src_off,
+                                                            const double* __restrict__ scale,
+                                                            const long* __restrict__ add_idx,
+                                                            const double* __restrict__ addends) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const int l = lat[k];
+  double v = scale[k] * p.src[(l >> 4) & 15][src_off[k]];
+  if (add_idx[k] >= 0) v = v + addends[add_idx[k]];
+  p.dst[l & 15][dst_off[k]] = v;
+}
+
+// wall terms of the sedimentation driver, one row of 9 per lattice row r, from the wall velocity
+//   uw = wa * u[:, r, col_a] + wb * u[:, r, col_b] + shift      (u: moment field [2][X][Y])
+// mode 0: factor * ((2 + 9 (uw.c_q)^2) - 3 uw.uw) w_q                              (:135, :149)
+// mode 1: factor * ((((1 + 3 uw.c_q) + 4.5 (uw.c_q)^2) - 1.5 uw.uw) w_q) * field[r]  (:202-208)
+__global__ __launch_bounds__(256) void k_wall_terms(double* __restrict__ out, const double* __restrict__ u,
+                                                    int X, int Y, int col_a, double wa, int col_b,
+                                                    double wb, double shift, int mode,
+                                                    const double* __restrict__ field, double factor) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= X) return;
+  const long N = (long)X * Y, a = (long)r * Y + col_a, b = (long)r * Y + col_b;
+  double w0, w1;
+  if (wb != 0.0) {
+    w0 = wa * u[a] - (-wb) * u[b];  // the driver writes 1.5 u[-1] - 0.5 u[-2]
+    w1 = wa * u[N + a] - (-wb) * u[N + b];
+  } else {
+    w0 = wa * u[a];
+    w1 = wa * u[N + a];
+  }
+  w0 = w0 + shift;
+  w1 = w1 + shift;
+  const double uu = w0 * w0 + w1 * w1;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double uc = w0 * (double)icx(q) + w1 * (double)icy(q);
+    double t;
+    if (mode == 0) t = ((2.0 + 9.0 * (uc * uc)) - 3.0 * uu) * wq(q);
+    else t = ((((1.0 + 3.0 * uc) + 4.5 * (uc * uc)) - 1.5 * uu) * wq(q)) * field[r];
+    out[(long)r * Q + q] = factor * t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_axpb(double* __restrict__ out, const double* __restrict__ in,
+                                              double a, double b, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a * in[i] + b;
+}
+
 // p[q][r][c] += ((1 - omega/2) ((a + b u.c_q)(F.c_q) - a u.F)) w_q on rows [row_begin, row_end)
 __global__ __launch_bounds__(256) void k_bgk_add_force_rows(double* __restrict__ p, Geom g,
                                                             const double* __restrict__ u, double omega,
@@ -57,10 +110,13 @@ struct lbm_links {
   // build phase: destination element -> source element, in insertion order of first appearance
   std::unordered_map<unsigned long long, size_t> slot;
   std::vector<int> lat;
-  std::vector<long> dst_off, src_off;
+  std::vector<long> dst_off, src_off, add_idx;
+  std::vector<double> scale;
+  bool affine = false;  // any link with scale != 1 or an addend
   int n = 0;
   int* d_lat = nullptr;
-  long *d_dst = nullptr, *d_src = nullptr;
+  long *d_dst = nullptr, *d_src = nullptr, *d_add = nullptr;
+  double* d_scale = nullptr;
 };
 
 using namespace lbm;
@@ -81,7 +137,15 @@ int lbm_links_create(lbm_links** out, int n_lattices, const lbm_geom* geoms) {
 
 int lbm_links_add(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, int dr, int dc, int src_lat,
                   int q_src, int sr0, int sc0, int sdr, int sdc, int count) {
+  return lbm_links_add_affine(t, dst_lat, q_dst, r0, c0, dr, dc, src_lat, q_src, sr0, sc0, sdr, sdc, count,
+                              1.0, -1, 0);
+}
+
+int lbm_links_add_affine(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, int dr, int dc,
+                         int src_lat, int q_src, int sr0, int sc0, int sdr, int sdc, int count,
+                         double scale, long long add0, long long add_stride) {
   LBM_REQUIRE(t && !t->d_lat, "lbm_links_add: NULL or already finalized table");
+  if (scale != 1.0 || add0 >= 0) t->affine = true;
   const int nl = (int)t->geoms.size();
   LBM_REQUIRE(dst_lat >= 0 && dst_lat < nl && src_lat >= 0 && src_lat < nl, "lbm_links_add: lattice index");
   LBM_REQUIRE(q_dst >= 0 && q_dst < 9 && q_src >= 0 && q_src < 9 && count >= 0, "lbm_links_add: bad population / count");
@@ -93,14 +157,19 @@ int lbm_links_add(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, int dr, 
     const long d = q_dst * gd.plane + gd.at(r, c), s = q_src * gs.plane + gs.at(sr, sc);
     const unsigned long long key = ((unsigned long long)dst_lat << 56) | (unsigned long long)d;
     auto it = t->slot.find(key);
+    const long ai = add0 >= 0 ? (long)(add0 + (long long)k * add_stride) : -1;
     if (it == t->slot.end()) {
       t->slot.emplace(key, t->lat.size());
       t->lat.push_back(dst_lat | (src_lat << 4));
       t->dst_off.push_back(d);
       t->src_off.push_back(s);
+      t->scale.push_back(scale);
+      t->add_idx.push_back(ai);
     } else {  // a later slice assignment overrides an earlier one at the same element
       t->lat[it->second] = dst_lat | (src_lat << 4);
       t->src_off[it->second] = s;
+      t->scale[it->second] = scale;
+      t->add_idx[it->second] = ai;
     }
   }
   return LBM_OK;
@@ -113,6 +182,14 @@ int lbm_links_finalize(lbm_links* t) {
   LBM_CHECK_HIP(hipMalloc(&t->d_lat, n * sizeof(int)));
   LBM_CHECK_HIP(hipMalloc(&t->d_dst, n * sizeof(long)));
   LBM_CHECK_HIP(hipMalloc(&t->d_src, n * sizeof(long)));
+  if (t->affine) {
+    LBM_CHECK_HIP(hipMalloc(&t->d_add, n * sizeof(long)));
+    LBM_CHECK_HIP(hipMalloc(&t->d_scale, n * sizeof(double)));
+    if (t->n) {
+      LBM_CHECK_HIP(hipMemcpy(t->d_add, t->add_idx.data(), t->n * sizeof(long), hipMemcpyHostToDevice));
+      LBM_CHECK_HIP(hipMemcpy(t->d_scale, t->scale.data(), t->n * sizeof(double), hipMemcpyHostToDevice));
+    }
+  }
   if (t->n) {
     LBM_CHECK_HIP(hipMemcpy(t->d_lat, t->lat.data(), t->n * sizeof(int), hipMemcpyHostToDevice));
     LBM_CHECK_HIP(hipMemcpy(t->d_dst, t->dst_off.data(), t->n * sizeof(long), hipMemcpyHostToDevice));
@@ -125,24 +202,56 @@ int lbm_links_finalize(lbm_links* t) {
 int lbm_links_count(const lbm_links* t) { return t ? (t->d_lat ? t->n : (int)t->lat.size()) : 0; }
 
 int lbm_links_apply(lbm_links* t, double* const* dst, const double* const* src, lbm_stream_t s) {
+  return lbm_links_apply_affine(t, dst, src, nullptr, s);
+}
+
+int lbm_links_apply_affine(lbm_links* t, double* const* dst, const double* const* src,
+                           const double* addends, lbm_stream_t s) {
   LBM_REQUIRE(t && t->d_lat && dst && src, "lbm_links_apply: NULL argument or table not finalized");
   if (!t->n) return LBM_OK;
+  if (t->affine) {
+    bool needs = false;
+    for (long a : t->add_idx) needs = needs || a >= 0;
+    LBM_REQUIRE(!needs || addends, "lbm_links_apply_affine: the table has addend links but addends is NULL");
+  }
   LinkPtrs p{};
   for (size_t i = 0; i < t->geoms.size(); ++i) {
     LBM_REQUIRE(dst[i] && src[i], "lbm_links_apply: NULL lattice %d", (int)i);
     p.dst[i] = dst[i];
     p.src[i] = src[i];
   }
-  LBM_KLAUNCH(k_links_apply, dim3((t->n + 255) / 256), dim3(256), 0, as_stream(s), p, t->n, t->d_lat, t->d_dst, t->d_src);
+  if (t->affine)
+    LBM_KLAUNCH(k_links_apply_affine, dim3((t->n + 255) / 256), dim3(256), 0, as_stream(s), p, t->n, t->d_lat, t->d_dst, t->d_src, t->d_scale, t->d_add, addends);
+  else
+    LBM_KLAUNCH(k_links_apply, dim3((t->n + 255) / 256), dim3(256), 0, as_stream(s), p, t->n, t->d_lat, t->d_dst, t->d_src);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
 
 int lbm_links_destroy(lbm_links* t) {
   if (!t) return LBM_OK;
-  for (void* p : {(void*)t->d_lat, (void*)t->d_dst, (void*)t->d_src})
+  for (void* p : {(void*)t->d_lat, (void*)t->d_dst, (void*)t->d_src, (void*)t->d_add, (void*)t->d_scale})
     if (p) (void)hipFree(p);
   delete t;
+  return LBM_OK;
+}
+
+int lbm_wall_terms(double* out, const double* u, int X, int Y, int col_a, double wa, int col_b, double wb,
+                   double shift, int mode, const double* field, double factor, lbm_stream_t s) {
+  LBM_REQUIRE(out && u && X > 0 && Y > 0, "lbm_wall_terms: bad argument");
+  LBM_REQUIRE(col_a >= 0 && col_a < Y && col_b >= 0 && col_b < Y, "lbm_wall_terms: column outside the lattice");
+  LBM_REQUIRE(mode == 0 || (mode == 1 && field), "lbm_wall_terms: mode %d (1 needs the per-row field)", mode);
+  LBM_KLAUNCH(k_wall_terms, dim3((X + 255) / 256), dim3(256), 0, as_stream(s), out, u, X, Y, col_a, wa, col_b,
+              wb, shift, mode, field, factor);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_axpb(double* out, const double* in, double a, double b, long long n, lbm_stream_t s) {
+  LBM_REQUIRE(out && in && n >= 0, "lbm_axpb: bad argument");
+  if (!n) return LBM_OK;
+  LBM_KLAUNCH(k_axpb, dim3(capped_grid((n + 255) / 256)), dim3(256), 0, as_stream(s), out, in, a, b, (long)n);
+  LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
 

@@ -572,6 +572,140 @@ void orc_ddl_run(int L, int nsteps, double omega, double Fr, double* fA, double*
 }
 
 // ---------------------------------------------------------------------------------
+// test/rectangle_sedimentation_test.cpp: fluid f + sediment concentration g (advection-diffusion
+// with settling velocity w_s), anti-bounce-back inlet / outlet columns, specular top, no-slip
+// bottom, a three-sided rectangular obstacle at hard-coded coordinates (:71-73)
+// ---------------------------------------------------------------------------------
+namespace {
+// the eight (dst, src) population pairs of :139-146 etc., in the driver's order
+const int ABB_DST[8] = {3, 4, 1, 2, 7, 8, 5, 6}, ABB_SRC[8] = {1, 2, 3, 4, 5, 6, 7, 8};
+inline void abb_terms(double* t, double uw0, double uw1) {  // :135 / :149
+  const double uu = uw0 * uw0 + uw1 * uw1;
+  for (int q = 0; q < 9; ++q) {
+    const double uc = uw0 * CX[q] + uw1 * CY[q];
+    t[q] = ((2.0 + 9.0 * (uc * uc)) - 3.0 * uu) * W9[q];
+  }
+}
+}  // namespace
+
+// nsteps iterations of :106-237; init != 0: build the driver's start state first (:79-103).
+// State: f, g = f_adve, g_adve [X][Y][9]; rho [X][Y], u [X][Y][2], C [X][Y].
+void orc_sed_steps(int X, int Y, double omega, double u_in, double w_s, double Cw, int init,
+                   int nsteps, double* f, double* g, double* rho, double* u, double* C) {
+  const size_t N = (size_t)X * Y;
+  small_grid_guard sg(N);
+  const int R23 = X - 151, C28 = 200, C38 = 250;  // :71-73 (R23 = -151 counted from the end)
+  std::vector<double> C_w(X, 0.0);
+  for (int r = X - 50; r < X; ++r) C_w[r] = Cw;  // :93
+  if (init) {
+    for (size_t i = 0; i < N; ++i) {
+      rho[i] = 1.0;
+      u[2 * i] = 0.0;
+      u[2 * i + 1] = u_in;  // :83
+      C[i] = 0.0;
+    }
+    for (int r = 0; r < X; ++r) C[nid(r, 0, Y)] = C_w[r];  // :94
+    orc_equilibrium(g, u, C, X, Y);                         // :95
+    orc_incomp_equilibrium(f, u, rho, X, Y);                // :100
+    orc_calc_rho(rho, f, X, Y);                             // :103-104
+    orc_calc_u(u, f, rho, X, Y);
+  }
+  std::vector<double> fe(N * 9), fc(N * 9), ge(N * 9), gc(N * 9), us(N * 2);
+  for (int t = 0; t < nsteps; ++t) {
+    orc_equilibrium(fe.data(), u, rho, X, Y);  // :123
+    for (size_t i = 0; i < 2 * N; ++i) us[i] = u[i] + w_s;
+    orc_equilibrium(ge.data(), us.data(), C, X, Y);        // :124
+    orc_collision(fc.data(), f, fe.data(), omega, X, Y);   // :130
+    orc_collision(gc.data(), g, ge.data(), omega / 1.0, X, Y);
+    // zero gradient (:136-140): top row, then the outlet column
+    for (int c = 0; c < Y; ++c)
+      for (int q = 0; q < 9; ++q) gc[nid(0, c, Y) * 9 + q] = gc[nid(1, c, Y) * 9 + q];
+    for (int r = 1; r < X - 1; ++r)
+      for (int q = 0; q < 9; ++q) gc[nid(r, Y - 1, Y) * 9 + q] = gc[nid(r, Y - 2, Y) * 9 + q];
+    advect(f, fc.data(), X, Y);  // :143-144
+    advect(g, gc.data(), X, Y);
+    {  // inlet, fixed wall velocity (0, u_in) (:148-159)
+      double a[9];
+      abb_terms(a, 0.0, u_in);
+      for (int r = 1; r < X - 1; ++r) {
+        const size_t i = nid(r, 0, Y) * 9;
+        for (int k = 0; k < 8; ++k) f[i + ABB_DST[k]] = -fc[i + ABB_SRC[k]] + a[ABB_SRC[k]];
+      }
+    }
+    for (int r = 0; r < X; ++r) {  // outlet, extrapolated wall velocity (:161-170)
+      const size_t l = nid(r, Y - 1, Y), m = nid(r, Y - 2, Y);
+      double a[9];
+      abb_terms(a, 1.5 * u[2 * l] - 0.5 * u[2 * m], 1.5 * u[2 * l + 1] - 0.5 * u[2 * m + 1]);
+      for (int k = 0; k < 8; ++k) f[l * 9 + ABB_DST[k]] = -fc[l * 9 + ABB_SRC[k]] + a[ABB_SRC[k]];
+    }
+    for (int c = 0; c < Y; ++c) {  // specular top (:173-175), no-slip bottom (:178-180)
+      const size_t a = nid(0, c, Y) * 9, b = nid(X - 1, c, Y) * 9;
+      f[a + 8] = fc[a + 7];
+      f[a + 1] = fc[a + 3];
+      f[a + 5] = fc[a + 6];
+      f[b + 7] = fc[b + 5];
+      f[b + 3] = fc[b + 1];
+      f[b + 6] = fc[b + 8];
+    }
+    for (int r = R23 + 1; r < X - 1; ++r) {  // first wall (:184-186)
+      const size_t i = nid(r, C28, Y) * 9;
+      f[i + 8] = fc[i + 6];
+      f[i + 4] = fc[i + 2];
+      f[i + 7] = fc[i + 5];
+    }
+    for (int c = C28; c < C38 + 1; ++c) {  // ceiling (:188-190)
+      const size_t i = nid(R23, c, Y) * 9;
+      f[i + 6] = fc[i + 8];
+      f[i + 3] = fc[i + 1];
+      f[i + 7] = fc[i + 5];
+    }
+    for (int r = R23 + 1; r < X - 1; ++r) {  // second wall (:192-194)
+      const size_t i = nid(r, C38, Y) * 9;
+      f[i + 5] = fc[i + 7];
+      f[i + 2] = fc[i + 4];
+      f[i + 6] = fc[i + 8];
+    }
+    orc_calc_rho(rho, f, X, Y);  // :197-198
+    orc_calc_u(u, f, rho, X, Y);
+    for (int r = 1; r < X - 1; ++r) {  // concentration inlet (:202-217)
+      const size_t i = nid(r, 0, Y);
+      const double w0 = u[2 * i] + w_s, w1 = u[2 * i + 1] + w_s, uu = w0 * w0 + w1 * w1;
+      for (int k = 0; k < 8; ++k) {
+        const int q = ABB_SRC[k];
+        const double uc = w0 * CX[q] + w1 * CY[q];
+        const double ga = ((((1.0 + 3.0 * uc) + 4.5 * (uc * uc)) - 1.5 * uu) * W9[q]) * C_w[r];
+        g[i * 9 + ABB_DST[k]] = -gc[i * 9 + q] + 2.0 * ga;
+      }
+    }
+    for (int r = R23 + 1; r < X; ++r) {  // first wall (to the last row, :220-222)
+      const size_t i = nid(r, C28, Y) * 9;
+      g[i + 8] = -gc[i + 6];
+      g[i + 4] = -gc[i + 2];
+      g[i + 7] = -gc[i + 5];
+    }
+    for (int c = C28; c < C38 + 1; ++c) {  // ceiling (:224-226)
+      const size_t i = nid(R23, c, Y) * 9;
+      g[i + 6] = -gc[i + 8];
+      g[i + 3] = -gc[i + 1];
+      g[i + 7] = -gc[i + 5];
+    }
+    for (int r = R23 + 1; r < X - 1; ++r) {  // second wall (:228-230)
+      const size_t i = nid(r, C38, Y) * 9;
+      g[i + 5] = -gc[i + 7];
+      g[i + 2] = -gc[i + 4];
+      g[i + 6] = -gc[i + 8];
+    }
+    for (int c = 0; c < Y; ++c) {  // bottom (:232-234)
+      const size_t i = nid(X - 1, c, Y) * 9;
+      g[i + 6] = gc[i + 8];
+      g[i + 3] = gc[i + 1];
+      g[i + 7] = gc[i + 5];
+    }
+    orc_calc_rho(C, g, X, Y);  // :235
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // ulbm::d2q9::kbc
 // ---------------------------------------------------------------------------------
 namespace {

@@ -66,6 +66,14 @@ void orc_ddm_run(int H, int W, int T, double omega, double rho_inlet, double rho
 void orc_ddl_run(int L, int nsteps, double omega, double Fr, double* fA, double* fB, double* fC,
                  double* fD, double* rho[4], double* u[4]);
 
+/* ---- test/rectangle_sedimentation_test.cpp:106-237: fluid f + sediment concentration g (settling
+ * velocity w_s added to BOTH velocity components, :124), anti-bounce-back inlet / outlet columns,
+ * zero-gradient copies on g_coll, specular top, no-slip bottom, the hard-coded rectangle (:71-73;
+ * needs X > 151, Y > 250).  PARITY UNPINNED: the driver needs toml++ (params). init != 0: build the
+ * start state (:79-104) first. */
+void orc_sed_steps(int X, int Y, double omega, double u_in, double w_s, double Cw, int init,
+                   int nsteps, double* f, double* g, double* rho, double* u, double* C);
+
 /* ---- ulbm::d2q9::kbc (src/ulbm.cpp:91-320) ---- */
 /* feq from (m0, ux, uy) with the caller-supplied ux2/uy2 (the ctor leaves them 0
  * for the driver's initialisation, ulbm_double_shear_flow.cpp:96). */

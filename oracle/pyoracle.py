@@ -201,6 +201,18 @@ class Oracle:
                              P4(*[_p(a) for a in rho]), P4(*[_p(a) for a in u]))
         return dict(f=f, rho=rho, u=u)
 
+    def sed_steps(self, X, Y, omega, u_in, nsteps, w_s=3e-3, Cw=1e-3, state=None):
+        """test/rectangle_sedimentation_test.cpp loop; state = dict(f, g, rho, u, C) or None (start)"""
+        if state is None:
+            st = dict(f=np.empty((X, Y, 9)), g=np.empty((X, Y, 9)), rho=np.empty((X, Y)),
+                      u=np.empty((X, Y, 2)), C=np.empty((X, Y)))
+        else:
+            st = {k: _c(v).copy() for k, v in state.items()}
+        self.lib.orc_sed_steps(X, Y, ct.c_double(omega), ct.c_double(u_in), ct.c_double(w_s), ct.c_double(Cw),
+                               int(state is None), int(nsteps), _p(st["f"]), _p(st["g"]), _p(st["rho"]),
+                               _p(st["u"]), _p(st["C"]))
+        return st
+
     def upo_steps(self, H, W, s2, rho_inlet, rho_outlet, nsteps, state=None):
         """test/ulbm_poiseuille.cpp loop; state = (f, m0, m1) to continue, None = the driver's start"""
         if state is None:

@@ -253,3 +253,36 @@ def test_decompose_domain_loop_driver_vs_unmodified_main(tmp_path):
             assert np.abs(ux - g[f"{blk}_ux_{kind}"][..., j]).max() < tol, (T, blk)
             assert np.abs(uy - g[f"{blk}_uy_{kind}"][..., j]).max() < tol, (T, blk)
             assert np.abs(rho - g[f"{blk}_rho_{kind}"][..., j]).max() < tol, (T, blk)
+
+
+@pytest.mark.parametrize("fast", [0, 1])
+def test_rectangle_sedimentation_driver_vs_oracle(tmp_path, oracle, fast):
+    """SURVEY 8(f) row 4, test/rectangle_sedimentation_test.cpp: fluid + sediment distributions, anti-
+    bounce-back columns with per-row wall terms, zero-gradient copies, the hard-coded obstacle --
+    drivers/rectangle_sedimentation_test.cpp on lbm_links_* (affine links) vs the oracle (PARITY
+    UNPINNED: the reference driver needs toml++).  540 x 420 lattice, 60 steps: bitwise in the
+    reference operation order, 1e-12 with the default reassociated collision."""
+    import json
+    toml = open(os.path.join(PKG, "examples", "parameters.toml")).read()
+    toml = toml.replace("characteristic_velocity = 0.5", "characteristic_velocity = 0.03")
+    toml = toml.replace("lattice_spacing = 2.0E-5", "lattice_spacing = 1.0E-4")
+    (tmp_path / "sed.toml").write_text(toml)
+    r = subprocess.run([os.path.join(BIN, "params_dump"), str(tmp_path / "sed.toml")], capture_output=True, text=True)
+    lp = json.loads(r.stdout)["lattice"]
+    X, Y = lp["X"], lp["Y"]
+    assert (X, Y) == (540, 420) and lp["u"] < 0.06
+    env = dict(os.environ, LBM_TUNE=f"bgk_fast={fast}")
+    steps = 60
+    r = subprocess.run([os.path.join(BIN, "rectangle_sedimentation_test"), str(tmp_path / "sed.toml"), "--steps", str(steps),
+                        "--dump", str(tmp_path / "sed")], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    want = oracle.sed_steps(X, Y, lp["omega"], lp["u"], steps)
+    got = dict(f=np.fromfile(tmp_path / "sed-f.f64").reshape(X, Y, 9), g=np.fromfile(tmp_path / "sed-g.f64").reshape(X, Y, 9),
+               rho=np.fromfile(tmp_path / "sed-rho.f64").reshape(X, Y), u=np.fromfile(tmp_path / "sed-u.f64").reshape(X, Y, 2),
+               C=np.fromfile(tmp_path / "sed-C.f64").reshape(X, Y))
+    for k in ("f", "g", "rho", "u", "C"):
+        if fast:
+            assert relerr(got[k], want[k]) < 1e-12, (k, relerr(got[k], want[k]))
+        else:
+            assert np.array_equal(got[k], want[k]), (k, float(np.abs(got[k] - want[k]).max()))
+    assert want["C"].max() > 1e-3 * 0.5 and np.isfinite(want["f"]).all()
