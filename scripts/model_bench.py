@@ -92,7 +92,7 @@ def bench_cg(R, C, n=20):
     lib.set_tuning(b"cg_strip", 0)
     tiles = os.environ.get("LBM_CG_TILES", "1").split(",")
     for tile in tiles:
-        for xcd in os.environ.get("LBM_CG_XCD", "1").split(","):
+        for xcd in os.environ.get("LBM_CG_XCD", "0").split(","):
             lib.set_tuning(b"cg_fused", 1)
             lib.set_tuning(b"cg_tile", int(tile))
             lib.set_tuning(b"cg_xcd", int(xcd))
