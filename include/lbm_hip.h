@@ -55,6 +55,16 @@ int lbm_event_destroy(void* ev);
 int lbm_event_record(void* ev, lbm_stream_t s);
 int lbm_event_elapsed_ms(float* ms, void* start, void* stop); /* synchronises on stop */
 
+/* ---- HIP graphs: capture a launch sequence of this library once, replay it per step -----------------
+ * Step calls only enqueue kernels, so a launch-bound loop (many small launches per step: small
+ * lattices, multi-block topologies) can be captured from a created (non-default) stream and
+ * replayed with one submission per step.  Pointers and parameters are frozen at capture time. */
+typedef struct lbm_graph lbm_graph;
+int lbm_graph_begin_capture(lbm_stream_t s);
+int lbm_graph_end_capture(lbm_stream_t s, lbm_graph** out);
+int lbm_graph_launch(lbm_graph* g, int times, lbm_stream_t s);
+int lbm_graph_destroy(lbm_graph* g);
+
 /* ---- layout converters (device buffers).  Q = 9 (f), 1 (rho), 2 (u) ---------------- */
 int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Q, lbm_stream_t s);
 int lbm_soa_to_aos(double* aos, const double* soa, int R, int C, int Q, lbm_stream_t s);

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <new>
 #include <string>
 
 #include "d2q9.hpp"
@@ -225,6 +226,52 @@ int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int d
   LBM_KLAUNCH(k_halo_copy, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, 1024)), dim3(256), 0, as_stream(s),
               lattice, buf, gg, t, 0);
   LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+// ---- HIP graphs: capture a driver's launch sequence once, replay it per step ---------------------
+// Every step call of this library only enqueues kernels (no allocation, no synchronisation), so a
+// launch-bound inner loop -- many small launches per step on a small lattice or a multi-block
+// topology -- can be captured from a (non-default) stream and replayed with one submission.
+struct lbm_graph {
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+int lbm_graph_begin_capture(lbm_stream_t s) {
+  LBM_REQUIRE(s, "lbm_graph_begin_capture: the default stream cannot be captured; create one with lbm_stream_create");
+  LBM_CHECK_HIP(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal));
+  return LBM_OK;
+}
+
+int lbm_graph_end_capture(lbm_stream_t s, lbm_graph** out) {
+  LBM_REQUIRE(s && out, "lbm_graph_end_capture: NULL argument");
+  hipGraph_t g = nullptr;
+  LBM_CHECK_HIP(hipStreamEndCapture(as_stream(s), &g));
+  hipGraphExec_t e = nullptr;
+  hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  if (err != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    set_error("lbm_graph_end_capture: hipGraphInstantiate failed: %s", hipGetErrorString(err));
+    return LBM_ERR_HIP;
+  }
+  lbm_graph* lg = new (std::nothrow) lbm_graph{g, e};
+  LBM_REQUIRE(lg, "lbm_graph_end_capture: out of host memory");
+  *out = lg;
+  return LBM_OK;
+}
+
+int lbm_graph_launch(lbm_graph* g, int times, lbm_stream_t s) {
+  LBM_REQUIRE(g && times >= 0, "lbm_graph_launch: bad argument");
+  for (int i = 0; i < times; ++i) LBM_CHECK_HIP(hipGraphLaunch(g->exec, as_stream(s)));
+  return LBM_OK;
+}
+
+int lbm_graph_destroy(lbm_graph* g) {
+  if (!g) return LBM_OK;
+  (void)hipGraphExecDestroy(g->exec);
+  (void)hipGraphDestroy(g->graph);
+  delete g;
   return LBM_OK;
 }
 

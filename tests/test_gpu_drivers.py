@@ -209,8 +209,9 @@ def test_decompose_domain_loop_driver_vs_oracle(tmp_path, oracle, fast):
     assert os.path.exists(exe)
     # the tuning switch is process-wide state of the library: hand it over through the environment
     env["LBM_TUNE"] = f"bgk_fast={fast}"
-    r = subprocess.run([exe, "--L", "128", "--T", "300", "--dump", str(tmp_path / "ddl")], capture_output=True,
-                       text=True, timeout=300, env=env)
+    # fast = 1 also replays the step as a captured HIP graph (lbm_graph_*): same bits as plain launches
+    r = subprocess.run([exe, "--L", "128", "--T", "300", "--graph", str(fast), "--dump", str(tmp_path / "ddl")],
+                       capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     want = oracle.ddl_run(128, 300)
     shapes = [(128, 32), (32, 64), (128, 32), (32, 64)]
