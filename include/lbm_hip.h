@@ -313,6 +313,11 @@ int lbm_ibm_create(lbm_ibm** out, const double* x, const double* y, int n_marker
 int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_markers, int m_max,
                         int X, int Y, int row_offset);
 int lbm_ibm_destroy(lbm_ibm* ib);
+/* EXTENSION without a reference counterpart (the reference's boundary is stationary, f_j = -2 rho_j u_j,
+ * SURVEY Q10): a uniform marker velocity U_b = (Ur, Uc) -- the boundary drags the fluid along,
+ * f_j = 2 rho_j (U_b - u_j), marker positions unchanged (a wall sliding in itself / a cylinder seen
+ * from a moving frame).  (0, 0) restores the reference behaviour bit for bit. */
+int lbm_ibm_set_velocity(lbm_ibm* ib, double Ur, double Uc);
 /* region of interest rows [r0, r1), columns [c0, c1)  (ibm.cpp:104-156) */
 int lbm_ibm_roi(const lbm_ibm* ib, int* r0, int* r1, int* c0, int* c1);
 /* eulerian_force_density (ibm.cpp:158-190): u[2][X][Y], rho[X][Y] device SoA ->

@@ -29,6 +29,8 @@ struct IbmDev {
   int n_touched;
   const int* tap_t;    // [n_markers][16] index into `touched` of each marker tap
   const int* tptr;     // [n_touched + 1] csr_ptr restricted to the touched nodes
+  double Ubx, Uby;     // marker velocity U_b (0 in the reference: stationary boundary)
+  int moving;          // U_b != 0
 };
 
 // u, rho of the ROI window copied out of the full fields (ibm.cpp:163-164); F_sum = 0
@@ -66,8 +68,13 @@ __global__ __launch_bounds__(64) void k_ibm_interp(IbmDev d, const double* __res
     ujy += w * u_roi[n + node];
     rhoj += w * rho_roi[node];
   }
-  fj[j] = -2.0 * rhoj * ujx;
-  fj[d.n_markers + j] = -2.0 * rhoj * ujy;
+  if (d.moving) {  // f_j = 2 rho_j (U_b - u_j): extension, no reference counterpart
+    fj[j] = 2.0 * rhoj * (d.Ubx - ujx);
+    fj[d.n_markers + j] = 2.0 * rhoj * (d.Uby - ujy);
+  } else {
+    fj[j] = -2.0 * rhoj * ujx;
+    fj[d.n_markers + j] = -2.0 * rhoj * ujy;
+  }
 }
 
 // per ROI node: F_n = sum over its (marker, tap) pairs in marker order (== the reference's
@@ -163,8 +170,13 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
         ujy += w * s_uy[t];
         rhoj += w * s_rho[t];
       }
-      s_fj[j] = -2.0 * rhoj * ujx;
-      s_fj[nm + j] = -2.0 * rhoj * ujy;
+      if (d.moving) {
+        s_fj[j] = 2.0 * rhoj * (d.Ubx - ujx);
+        s_fj[nm + j] = 2.0 * rhoj * (d.Uby - ujy);
+      } else {
+        s_fj[j] = -2.0 * rhoj * ujx;
+        s_fj[nm + j] = -2.0 * rhoj * ujy;
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -358,7 +370,7 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
                  di + box0.size(), di + box0.size() + csr_ptr.size(), dd + phi.size(),
                  di + box0.size() + csr_ptr.size() + nnz, (int)touched.size(),
                  di + box0.size() + csr_ptr.size() + nnz + touched.size(),
-                 di + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size()};
+                 di + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size(), 0.0, 0.0, 0};
   *out = ib;
   return LBM_OK;
 }
@@ -369,6 +381,14 @@ int lbm_ibm_destroy(lbm_ibm* ib) {
                   (void*)ib->fj, (void*)ib->out2})
     if (p) (void)hipFree(p);
   delete ib;
+  return LBM_OK;
+}
+
+int lbm_ibm_set_velocity(lbm_ibm* ib, double Ur, double Uc) {
+  LBM_REQUIRE(ib, "lbm_ibm_set_velocity: NULL boundary");
+  ib->d.Ubx = Ur;
+  ib->d.Uby = Uc;
+  ib->d.moving = (Ur != 0.0 || Uc != 0.0) ? 1 : 0;
   return LBM_OK;
 }
 

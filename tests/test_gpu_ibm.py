@@ -177,3 +177,40 @@ def test_cylinder_two_slabs_equal_single_block(lib, oracle, owner):
     assert bits_equal(got, fo), ulp_diff(got, fo)
     assert np.allclose(ib0.surface_force(), Fso, rtol=1e-11, atol=1e-16)
     ib0.close(); ib_flat.close()
+
+
+def test_moving_boundary_extension(lib, oracle):
+    """BASELINE config 5 says "moving boundary"; the reference's boundary is stationary (Q10).  The
+    extension lbm_ibm_set_velocity gives the markers a uniform velocity U_b (f_j = 2 rho_j (U_b - u_j)):
+    (0, 0) must reproduce the stationary run bit for bit; with U_b = the inflow velocity the
+    boundary no longer resists the stream (surface force ~ 0); with U_b against it the drag grows."""
+    X, Y, omega, u_in = 160, 128, 1.0 / 0.6, 0.04
+    t = 2 * np.pi * np.arange(60) / 60
+    x, y = X / 3.0 + 10 * np.cos(t), Y / 2.0 + 10 * np.sin(t)
+    bc = pylbm.Bc.periodic()
+    bc.row_lo = bc.row_hi = pylbm.EDGE_ABB_VELOCITY
+    bc.col_lo = bc.col_hi = pylbm.EDGE_SPECULAR
+    bc.uw_r = u_in
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+
+    def run(Ub):
+        sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1), bc=bc)
+        ib = pylbm.Ibm(lib, x, y, X, Y)
+        if Ub is not None:
+            lib.ibm_set_velocity(ib.h, ct.c_double(Ub[0]), ct.c_double(Ub[1]))
+        sv.attach_ibm(ib)
+        sv.set_f(f0)
+        sv.step(60)
+        f, Fs = sv.get_f(), ib.surface_force()
+        sv.close(); ib.close()
+        return f, Fs
+
+    f_ref, Fs_ref = run(None)
+    f_zero, Fs_zero = run((0.0, 0.0))
+    assert bits_equal(f_zero, f_ref) and np.array_equal(Fs_zero, Fs_ref)
+    _, Fs_co = run((u_in, 0.0))
+    _, Fs_counter = run((-u_in, 0.0))
+    assert Fs_ref[0] < 0                                   # F acts on the fluid: the stationary cylinder resists the +r stream
+    assert abs(Fs_co[0]) < 0.05 * abs(Fs_ref[0])           # co-moving markers: almost no force
+    assert Fs_counter[0] < 1.5 * Fs_ref[0]                 # counter-moving: larger resistance (more negative)
