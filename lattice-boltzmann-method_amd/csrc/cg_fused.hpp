@@ -266,9 +266,17 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
   // cache lines on both sides of a 32-column tile: 2x read amplification when every XCD fetches
   // them on its own), so XCD k gets the k-th contiguous eighth of the tile sequence.
   int tile = blockIdx.x;
-  if (xcd_swizzle) {
+  if (xcd_swizzle == 1) {  // XCD k gets the k-th contiguous eighth of the tile sequence
     const int per = gridDim.x / 8;
     if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+  } else if (xcd_swizzle > 1) {
+    // groups of G column-neighbour tiles per XCD, all XCDs inside the same window of 8 G tiles:
+    // workgroup b runs on XCD b % 8 as its (b / 8)-th block; consecutive blocks of an XCD get
+    // consecutive tiles of a group, so the shared ring lines are L2 hits, while the eight XCDs
+    // keep streaming through the same region of the lattice
+    const int G = xcd_swizzle, x = tile % 8, m = tile / 8, win = 8 * G;
+    const int t2 = (m / G) * win + x * G + (m % G);
+    if ((m / G + 1) * win <= (int)gridDim.x) tile = t2;
   }
   const int r_base = row_begin + (tile / tiles_c) * TR, c_base = (tile % tiles_c) * TC;
   const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
