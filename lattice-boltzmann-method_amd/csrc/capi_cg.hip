@@ -82,7 +82,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
                              double* rho_b, double* u, double* psi, double* snu, const MacroIdx& mi,
                              int row_begin, int row_end, hipStream_t st) {
   const int tiles = ((row_end - row_begin + TR - 1) / TR) * ((g.C + TC - 1) / TC);
-  const int xs = tuning("cg_xcd", 0);  // measured: +8 % for 8x64 tiles, -10 % for the default 16x32
+  const int xs = tuning("cg_xcd", 2);  // pairs of column-neighbour tiles per XCD: +5 % at 4 waves per SIMD
   if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
   else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
   LBM_CHECK_LAUNCH();
@@ -202,12 +202,12 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
     case 4: return launch_cg_strip_t<4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     default: return launch_cg_strip_t<1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
   }
-  switch (tuning("cg_tile", 1)) {
+  switch (tuning("cg_tile", 4)) {  // default: 16x32 tiles budgeted for 4 waves per SIMD (128 VGPRs)
     case 0: return launch_cg_fused_t<8, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 2: return launch_cg_fused_t<8, 64, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 3: return launch_cg_fused_t<16, 32, 3>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
-    case 4: return launch_cg_fused_t<16, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
-    default: return launch_cg_fused_t<16, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 1: return launch_cg_fused_t<16, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    default: return launch_cg_fused_t<16, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
   }
 }
 

@@ -90,9 +90,9 @@ def bench_cg(R, C, n=20):
             report("colour-gradient MRT (one launch per step, column strips, %s wave(s)/block, %s rows/chunk)" % (strip, rows), R, C, dt, 288)
     lib.set_tuning(b"cg_rows", -1)
     lib.set_tuning(b"cg_strip", 0)
-    tiles = os.environ.get("LBM_CG_TILES", "1").split(",")
+    tiles = os.environ.get("LBM_CG_TILES", "4").split(",")
     for tile in tiles:
-        for xcd in os.environ.get("LBM_CG_XCD", "0").split(","):
+        for xcd in os.environ.get("LBM_CG_XCD", "2").split(","):
             lib.set_tuning(b"cg_fused", 1)
             lib.set_tuning(b"cg_tile", int(tile))
             lib.set_tuning(b"cg_xcd", int(xcd))
