@@ -213,25 +213,38 @@ __global__ __launch_bounds__(256, LBM_CG_WAVES) void k_cg_collide(
   const int r = r_base + tr, c = c_base + tc;
   if (r >= row_end || c >= g.C) return;
 
-  // 5x5 cross-correlations, taps in (i, j) row-major order as conv2d lays them out
+  // 5x5 cross-correlations, taps in (i, j) row-major order as conv2d lays them out.  The row loop is
+  // NOT unrolled (the weights come from a constant table, same values as the folded constants):
+  // fully unrolled, the scheduler hoists all 100 LDS reads above the collision and the kernel needs
+  // 274 VGPRs + AGPR spills; the accumulation order per sum is unchanged, so results are too.
   double gx = 0.0, gy = 0.0, dxq[2] = {0.0, 0.0}, dyq[2] = {0.0, 0.0};
+  {
+    constexpr double kx[5][5] = {
+        {(1.0 / 5040.0) * cg_xi(0, 0), (1.0 / 5040.0) * cg_xi(0, 1), (1.0 / 5040.0) * cg_xi(0, 2), (1.0 / 5040.0) * cg_xi(0, 3), (1.0 / 5040.0) * cg_xi(0, 4)},
+        {(1.0 / 5040.0) * cg_xi(1, 0), (1.0 / 5040.0) * cg_xi(1, 1), (1.0 / 5040.0) * cg_xi(1, 2), (1.0 / 5040.0) * cg_xi(1, 3), (1.0 / 5040.0) * cg_xi(1, 4)},
+        {(1.0 / 5040.0) * cg_xi(2, 0), (1.0 / 5040.0) * cg_xi(2, 1), (1.0 / 5040.0) * cg_xi(2, 2), (1.0 / 5040.0) * cg_xi(2, 3), (1.0 / 5040.0) * cg_xi(2, 4)},
+        {(1.0 / 5040.0) * cg_xi(3, 0), (1.0 / 5040.0) * cg_xi(3, 1), (1.0 / 5040.0) * cg_xi(3, 2), (1.0 / 5040.0) * cg_xi(3, 3), (1.0 / 5040.0) * cg_xi(3, 4)},
+        {(1.0 / 5040.0) * cg_xi(4, 0), (1.0 / 5040.0) * cg_xi(4, 1), (1.0 / 5040.0) * cg_xi(4, 2), (1.0 / 5040.0) * cg_xi(4, 3), (1.0 / 5040.0) * cg_xi(4, 4)}};
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i) {
+      const double di = (double)(i - 2);
 #pragma unroll
-  for (int i = 0; i < 5; ++i)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const double wx = ((1.0 / 5040.0) * cg_xi(i, j)) * (double)(i - 2);  // d/d(row)  ("x")
-      const double wy = ((1.0 / 5040.0) * cg_xi(i, j)) * (double)(j - 2);  // d/d(col)  ("y")
-      if (i != 2) {
-        gx += wx * s_psi[tr + i][tc + j];
-        dxq[0] += wx * s_q[0][tr + i][tc + j];
-        dxq[1] += wx * s_q[2][tr + i][tc + j];
-      }
-      if (j != 2) {
-        gy += wy * s_psi[tr + i][tc + j];
-        dyq[0] += wy * s_q[1][tr + i][tc + j];
-        dyq[1] += wy * s_q[3][tr + i][tc + j];
+      for (int j = 0; j < 5; ++j) {
+        const double wx = kx[i][j] * di;                  // d/d(row)  ("x")
+        const double wy = kx[i][j] * (double)(j - 2);     // d/d(col)  ("y")
+        if (i != 2) {
+          gx += wx * s_psi[tr + i][tc + j];
+          dxq[0] += wx * s_q[0][tr + i][tc + j];
+          dxq[1] += wx * s_q[2][tr + i][tc + j];
+        }
+        if (j != 2) {
+          gy += wy * s_psi[tr + i][tc + j];
+          dyq[0] += wy * s_q[1][tr + i][tc + j];
+          dyq[1] += wy * s_q[3][tr + i][tc + j];
+        }
       }
     }
+  }
 
   const long o = mi.at(r, c);
   const double rr = rho_r[o], rb = rho_b[o], ux = u[o], uy = u[n + o];
