@@ -477,7 +477,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * "rows" (rows per thread 1/2/4, default 1), "grid_cap" (variants 1-2); two-step LDS kernel:
  * "tb_rows" (tile height, default 8), "tb_block" (default 512), "tb_order"; sliding-window kernel:
  * "sw_rows" (rows per wavefront chunk, default 64), "sw_waves" (waves per workgroup, default 4; 2 for
- * the reassociated BGK model);
+ * the reassociated BGK model), "sw_xcd" (G > 0: G consecutive strip groups per XCD; measured no effect);
  * "solver_depth" (steps lbm_solver_step fuses per launch on periodic BGK blocks, default 5, 1 =
  * off).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);

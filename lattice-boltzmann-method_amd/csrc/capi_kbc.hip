@@ -138,9 +138,9 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   const int n_waves = (int)n_waves_l;
   const dim3 grid((n_waves + 1) / 2);
   switch (depth) {
-    case 2: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); break;
-    case 3: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); break;
-    default: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 4, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); break;
+    case 2: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
+    case 3: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
+    default: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 4, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
   }
   LBM_CHECK_LAUNCH();
   return LBM_OK;

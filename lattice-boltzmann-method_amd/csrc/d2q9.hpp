@@ -606,9 +606,17 @@ __host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 :
 template <class Model, int D, int WAVES, bool NT_STORE>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
-    int row_end, int rows_per_chunk, int strips, int n_waves) {
+    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group) {
   constexpr int W = 64 - 2 * (D - 1);  // valid output columns per wave
-  const int wave = blockIdx.x * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th block.  xcd_group = G > 0: consecutive
+  // blocks of one XCD take G consecutive strip groups, so the 128-B lines that neighbouring strips
+  // share (a strip's 64 columns start 8 doubles before a line boundary) are fetched once per L2
+  int blk = blockIdx.x;
+  if (xcd_group > 0) {
+    const int x = blk % 8, mth = blk / 8, win = 8 * xcd_group;
+    if ((mth / xcd_group + 1) * win <= (int)gridDim.x) blk = (mth / xcd_group) * win + x * xcd_group + mth % xcd_group;
+  }
+  const int wave = blk * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wave >= n_waves) return;
   const int strip = wave % strips, chunk = wave / strips;
   const int R0 = row_begin + chunk * rows_per_chunk;

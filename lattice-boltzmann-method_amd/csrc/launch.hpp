@@ -182,8 +182,8 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
-    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves); \
-    else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves);   \
+    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
+    else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0));   \
   } else
   LBM_SW(2, 4) LBM_SW(3, 4) LBM_SW(4, 4) LBM_SW(5, 4) LBM_SW(6, 4)
   LBM_SW(2, 1) LBM_SW(3, 1) LBM_SW(4, 1) LBM_SW(2, 2) LBM_SW(3, 2) LBM_SW(4, 2) LBM_SW(5, 2) LBM_SW(6, 2) {
