@@ -150,10 +150,14 @@ int lbm_links_add_affine(lbm_links* t, int dst_lat, int q_dst, int r0, int c0, i
   LBM_REQUIRE(dst_lat >= 0 && dst_lat < nl && src_lat >= 0 && src_lat < nl, "lbm_links_add: lattice index");
   LBM_REQUIRE(q_dst >= 0 && q_dst < 9 && q_src >= 0 && q_src < 9 && count >= 0, "lbm_links_add: bad population / count");
   const Geom gd = make_geom(t->geoms[dst_lat]), gs = make_geom(t->geoms[src_lat]);
-  for (int k = 0; k < count; ++k) {
+  for (int k : {0, count - 1}) {  // the slice is linear: its two ends decide; nothing is added on failure
+    if (count == 0) break;
     const int r = r0 + k * dr, c = c0 + k * dc, sr = sr0 + k * sdr, sc = sc0 + k * sdc;
     LBM_REQUIRE(r >= 0 && r < gd.R && c >= 0 && c < gd.C && sr >= 0 && sr < gs.R && sc >= 0 && sc < gs.C,
                 "lbm_links_add: slice leaves the lattice (dst %d,%d of %dx%d; src %d,%d of %dx%d)", r, c, gd.R, gd.C, sr, sc, gs.R, gs.C);
+  }
+  for (int k = 0; k < count; ++k) {
+    const int r = r0 + k * dr, c = c0 + k * dc, sr = sr0 + k * sdr, sc = sc0 + k * sdc;
     const long d = q_dst * gd.plane + gd.at(r, c), s = q_src * gs.plane + gs.at(sr, sc);
     const unsigned long long key = ((unsigned long long)dst_lat << 56) | (unsigned long long)d;
     auto it = t->slot.find(key);

@@ -57,3 +57,40 @@ def test_header_is_plain_c99(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
                            str(src), "-L", libdir, "-llbm_hip", f"-Wl,-rpath,{libdir}", "-o", str(exe)])
     assert subprocess.call([str(exe)]) == 0
+
+
+def test_newer_entry_points_validate_before_touching_the_gpu():
+    """links / graph / ring / two-phase / KBC entry points reject bad arguments on the host"""
+    lib = pylbm.Lib()
+    g = pylbm.Geom(16, 16, 0)
+    t = ct.c_void_p()
+    with pytest.raises(pylbm.LbmError, match="1..8 lattices"):
+        lib.links_create(ct.byref(t), 9, ct.byref(g))
+    lib.links_create(ct.byref(t), 1, ct.byref(g))
+    try:
+        with pytest.raises(pylbm.LbmError, match="slice leaves the lattice"):
+            lib.links_add(t, 0, 1, 0, 0, 1, 0, 0, 3, 10, 0, 1, 0, 8)      # source rows 10..17 of 16
+        with pytest.raises(pylbm.LbmError, match="population"):
+            lib.links_add(t, 0, 9, 0, 0, 1, 0, 0, 3, 0, 0, 1, 0, 4)
+        lib.links_add(t, 0, 1, 0, 0, 0, 1, 0, 3, 0, 0, 0, 1, 16)
+        lib.links_add(t, 0, 1, 0, 0, 0, 1, 0, 5, 0, 0, 0, 1, 16)          # overrides the same 16 elements
+        assert lib.raw.lbm_links_count(t) == 16
+        with pytest.raises(pylbm.LbmError, match="not finalized"):
+            lib.links_apply(t, None, None, None)
+    finally:
+        lib.links_destroy(t)
+    with pytest.raises(pylbm.LbmError, match="default stream cannot be captured"):
+        lib.graph_begin_capture(None)
+    ring = ct.c_void_p()
+    ident = (ct.c_ubyte * 128)()
+    with pytest.raises(pylbm.LbmError, match="rank 3 of 2"):
+        lib.ring_create(ct.byref(ring), ident, 3, 2, ct.byref(pylbm.Geom(16, 16, 1)), 1)
+    with pytest.raises(pylbm.LbmError, match="ghost rows"):
+        lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
+    prm = pylbm.KbcParams(1.9)
+    with pytest.raises(pylbm.LbmError, match="supported: 2..4"):
+        lib.kbc_stream_collide_xn(None, None, ct.byref(g), None, ct.byref(prm), 7, 0, 16, None)
+    cg = pylbm.cg_params()
+    with pytest.raises(pylbm.LbmError, match="0 or 3 ghost rows"):
+        lib.cg_step_fused(None, None, None, None, ct.byref(pylbm.Geom(16, 16, 2)), None, ct.byref(cg), 0, 16,
+                          None, None, None, None, None, None)
