@@ -390,6 +390,9 @@ int lbm_ring_join(lbm_ring* rg, lbm_stream_t main);
  * window); bc: the physical edges of the GLOBAL domain (NULL = periodic), seams become HALO */
 int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
                       const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
+/* the same for KBC (n_steps 1, or 2..4 with the reassociated collision) */
+int lbm_ring_kbc_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                      const lbm_kbc_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
 
 /* one overlapped step of a two-phase (colour-gradient) slab: lbm_cg_step_fused on edge and interior
  * rows + ONE exchange of the 3 ghost rows of both colours (slab ghost must be 3; bc NULL = the

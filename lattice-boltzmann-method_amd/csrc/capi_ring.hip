@@ -258,25 +258,15 @@ int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* s
   return LBM_OK;
 }
 
-// One launch-step of the BGK slab with overlap: edge rows (edge stream), interior rows (main
-// stream, concurrently), halo exchange of dst behind the edge rows.  n_steps = 1: single-step
-// kernel (ghost >= 1); n_steps >= 2: sliding-window kernel (ghost >= n_steps).  On return `main`
-// has been made to wait for everything: the next call may follow immediately.
-int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
-                      const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s) {
-  LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_bgk_step: NULL argument");
-  const int R = rg->g.R, G = rg->g.ghost;
-  LBM_REQUIRE(n_steps >= 1 && n_steps <= G, "lbm_ring_bgk_step: %d steps with %d ghost rows", n_steps, G);
-  if (edge_rows < G) edge_rows = G;
-  LBM_REQUIRE(2 * edge_rows < R, "lbm_ring_bgk_step: edge_rows=%d too large for %d rows", edge_rows, R);
-  hipStream_t main = as_stream(main_s);
-  lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
-  if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
-  if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
-  auto rows = [&](int r0, int r1, hipStream_t st) -> int {
-    if (n_steps == 1) return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
-    return lbm_bgk_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
-  };
+}  // extern "C"
+
+// One launch-step of a slab with overlap: edge rows (edge stream), interior rows (main stream,
+// concurrently), halo exchange of dst behind the edge rows.  `rows(r0, r1, stream)` launches the
+// model's kernel on a row range.  On return `main` has been made to wait for everything: the next
+// call may follow immediately.
+template <class Rows>
+static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows) {
+  const int R = rg->g.R;
   // edge stream starts after everything previously enqueued on main (src complete)
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
@@ -288,6 +278,44 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
   LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
   return LBM_OK;
+}
+
+extern "C" {
+
+// BGK: n_steps = 1: single-step kernel (ghost >= 1); n_steps >= 2: sliding-window kernel
+// (ghost >= n_steps).
+int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                      const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_bgk_step: NULL argument");
+  const int R = rg->g.R, G = rg->g.ghost;
+  LBM_REQUIRE(n_steps >= 1 && n_steps <= G, "lbm_ring_bgk_step: %d steps with %d ghost rows", n_steps, G);
+  if (edge_rows < G) edge_rows = G;
+  LBM_REQUIRE(2 * edge_rows < R, "lbm_ring_bgk_step: edge_rows=%d too large for %d rows", edge_rows, R);
+  lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
+  if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
+  if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  return ring_step(rg, dst, edge_rows, as_stream(main_s), [&](int r0, int r1, hipStream_t st) -> int {
+    if (n_steps == 1) return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
+    return lbm_bgk_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
+  });
+}
+
+// KBC: the same schedule (n_steps 1, or 2..4 through the sliding window with the reassociated
+// collision)
+int lbm_ring_kbc_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                      const lbm_kbc_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_kbc_step: NULL argument");
+  const int R = rg->g.R, G = rg->g.ghost;
+  LBM_REQUIRE(n_steps >= 1 && n_steps <= G && n_steps <= 4, "lbm_ring_kbc_step: %d steps with %d ghost rows (max 4)", n_steps, G);
+  if (edge_rows < G) edge_rows = G;
+  LBM_REQUIRE(2 * edge_rows < R, "lbm_ring_kbc_step: edge_rows=%d too large for %d rows", edge_rows, R);
+  lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
+  if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
+  if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  return ring_step(rg, dst, edge_rows, as_stream(main_s), [&](int r0, int r1, hipStream_t st) -> int {
+    if (n_steps == 1) return lbm_kbc_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
+    return lbm_kbc_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
+  });
 }
 
 // One overlapped single-step launch of a BGK slab that may own an immersed boundary (config 5:

@@ -201,3 +201,53 @@ def test_kbc_multi_step_launches_equal_single_steps(lib, oracle):
     want, _, _ = oracle.kbc_steps(f0, m0, oracle.calc_u(f0, m0), S2, 21)
     assert relerr(sv.get_f(), want) < 1e-12
     sv.close()
+
+
+def test_native_ring_kbc_self_exchange(lib, oracle):
+    """lbm_ring_kbc_step (C++ slab ring on RCCL, csrc/capi_ring.hip): one periodic rank whose
+    neighbours are itself, 3-step launches and single steps; equals the single-block solver bit for
+    bit (same collision, same kernels) and the oracle to the reassociated tolerance."""
+    d = dev()
+    R, C = 96, 256
+    rng = np.random.default_rng(5)
+    rho = 1 + 0.01 * rng.standard_normal((R, C))
+    u = 0.03 * rng.standard_normal((R, C, 2))
+    f0 = oracle.equilibrium(u, rho) * (1 + 0.01 * rng.standard_normal((R, C, 9)))
+    prm = pylbm.KbcParams(S2)
+    flat = pylbm.Geom(R, C, 0)
+    ident = (ct.c_ubyte * 128)()
+    for depth, launches in ((3, 3), (1, 4)):
+        n = depth * launches
+        # reference: the same number of single steps on one ghost-free block
+        a = upload_soa(lib, f0)
+        tmp = torch.empty_like(a)
+        lib.kbc_collide(_ptr(tmp), _ptr(a), ct.byref(flat), None, ct.byref(prm), None, None, None)
+        first = tmp.clone()
+        for _ in range(n):
+            lib.kbc_stream_collide(_ptr(a), _ptr(tmp), ct.byref(flat), None, ct.byref(prm), 0, R, None, None, None)
+            a, tmp = tmp, a
+        torch.cuda.synchronize()
+        want = tmp
+        g = pylbm.Geom(R, C, depth)
+        lat = [torch.zeros((9, R + 2 * depth, C), dtype=torch.float64, device=d) for _ in range(2)]
+        lat[0][:, depth:depth + R] = first
+        ring = ct.c_void_p()
+        lib.ring_unique_id(ident)
+        lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
+        try:
+            torch.cuda.synchronize()
+            lib.ring_exchange(ring, _ptr(lat[0]), None)
+            lib.ring_join(ring, None)
+            cur = 0
+            for _ in range(launches):
+                lib.ring_kbc_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), None, ct.byref(prm), depth, 16, None)
+                cur ^= 1
+            torch.cuda.synchronize()
+            assert torch.equal(lat[cur][:, depth:depth + R], want), (depth, float((lat[cur][:, depth:depth + R] - want).abs().max()))
+        finally:
+            lib.ring_destroy(ring)
+    m0 = oracle.calc_rho(f0)
+    fo, _, _ = oracle.kbc_steps(f0, m0, oracle.calc_u(f0, m0), S2, 5)   # 1 collide + 4 stream-collides, streamed
+    out = torch.empty((9, R, C), dtype=torch.float64, device=d)
+    lib.stream(_ptr(out), _ptr(want.contiguous()), ct.byref(flat), None, None)
+    assert relerr(download_aos(lib, out), fo) < 1e-12
