@@ -6,7 +6,8 @@
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_box --id-file /tmp/x [...]   under any launcher
 //
 // Options: --rows R (per GPU, weak scaling) --cols C --steps K (launch-steps timed) --warmup W
-//          --depth D (time steps per launch = ghost rows, 1..6) --edge-rows E --omega w
+//          --depth D (time steps per launch = ghost rows, 1..6; KBC: 1..4) --edge-rows E --omega w
+//          --model bgk|kbc (kbc: the entropic KBC collision with s2 = omega, config 3 over slabs)
 //          --check 1 (N ranks vs rank 0 recomputing the whole box: small sizes only)
 //
 // The block binding this generalises: test/decompose_domain.cpp:181-187 (3 populations per
@@ -50,6 +51,7 @@ void init_node(double* f9, int gr, int c, int Rg, int C) {
 struct Args {
   int rows = 8192, cols = 8192, steps = 20, warmup = 5, depth = 5, edge_rows = 32, check = 0;
   double omega = 1.2;
+  bool kbc = false;
   std::string id_file;
 };
 
@@ -71,7 +73,12 @@ double* make_slab(const Args& a, int R, int row0, int Rg, const lbm_geom& g, con
   check(lbm_memset(post, 0, 9 * plane * sizeof(double), nullptr), "memset");
   // the collide-only launch that opens the post-collision-resident loop (ghost rows: collide of
   // zeros stays in the ghost rows and is overwritten by the first exchange)
-  check(lbm_bgk_collide(post, pre, &g, nullptr, &prm, nullptr, nullptr, nullptr), "lbm_bgk_collide");
+  if (a.kbc) {
+    lbm_kbc_params kp{prm.omega};
+    check(lbm_kbc_collide(post, pre, &g, nullptr, &kp, nullptr, nullptr, nullptr), "lbm_kbc_collide");
+  } else {
+    check(lbm_bgk_collide(post, pre, &g, nullptr, &prm, nullptr, nullptr, nullptr), "lbm_bgk_collide");
+  }
   check(lbm_stream_sync(nullptr), "sync");
   lbm_free(pre);
   return post;
@@ -83,6 +90,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   lbm_geom g{R, C, D, 0};
   lbm_bgk_params prm{};
   prm.omega = a.omega;
+  lbm_kbc_params kprm{a.omega};
 
   unsigned char id[128];
   if (rank == 0) {
@@ -104,8 +112,8 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
 
   int cur = 0;
   auto launch = [&]() {
-    check(lbm_ring_bgk_step(ring, lat[cur ^ 1], lat[cur], nullptr, &prm, D, a.edge_rows, nullptr),
-          "lbm_ring_bgk_step");
+    if (a.kbc) check(lbm_ring_kbc_step(ring, lat[cur ^ 1], lat[cur], nullptr, &kprm, D, a.edge_rows, nullptr), "lbm_ring_kbc_step");
+    else check(lbm_ring_bgk_step(ring, lat[cur ^ 1], lat[cur], nullptr, &prm, D, a.edge_rows, nullptr), "lbm_ring_bgk_step");
     cur ^= 1;
   };
   for (int i = 0; i < a.warmup; ++i) launch();
@@ -148,7 +156,8 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
       check(lbm_malloc((void**)&q2, n * sizeof(double)), "lbm_malloc");
       const int total = (a.warmup + a.steps) * D;
       for (int t = 0; t < total; ++t) {
-        check(lbm_bgk_stream_collide(q2, p, &gw, nullptr, &prm, 0, Rg, nullptr, nullptr, nullptr), "ref step");
+        if (a.kbc) check(lbm_kbc_stream_collide(q2, p, &gw, nullptr, &kprm, 0, Rg, nullptr, nullptr, nullptr), "ref step");
+        else check(lbm_bgk_stream_collide(q2, p, &gw, nullptr, &prm, 0, Rg, nullptr, nullptr, nullptr), "ref step");
         std::swap(p, q2);
       }
       std::vector<double> want(n);
@@ -168,10 +177,10 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
 
   if (rank == 0) {
     const double lups = (double)Rg * C * D * a.steps / tmax;
-    std::printf("{\"driver\": \"slab_ring_box\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, "
+    std::printf("{\"driver\": \"slab_ring_box\", \"model\": \"%s\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, "
                 "\"depth\": %d, \"launches\": %d, \"ms_per_launch\": %.4f, \"mlups\": %.1f, "
                 "\"transport\": \"rccl send/recv (C++ ring)\"%s}\n",
-                world, R, C, D, a.steps, 1e3 * tmax / a.steps, lups / 1e6,
+                a.kbc ? "kbc" : "bgk", world, R, C, D, a.steps, 1e3 * tmax / a.steps, lups / 1e6,
                 a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
     std::fflush(stdout);
   }
@@ -193,6 +202,8 @@ int main(int argc, char** argv) {
   a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "32").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
   a.omega = std::atof(arg_value(argc, argv, "--omega", "1.2").c_str());
+  a.kbc = arg_value(argc, argv, "--model", "bgk") == "kbc";
+  if (a.kbc && a.depth > 4) a.depth = 3;
   a.id_file = arg_value(argc, argv, "--id-file", "/tmp/lbm_ring_id." + std::to_string((long)getpid()));
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
   try {

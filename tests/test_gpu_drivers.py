@@ -141,10 +141,10 @@ def test_slab_ring_box_driver_self_ring(tmp_path):
     import json
     exe = os.path.join(BIN, "slab_ring_box")
     assert os.path.exists(exe)
-    for depth, edge in ((5, 16), (1, 8)):
-        r = subprocess.run([exe, "--spawn", "1", "--rows", "160", "--cols", "256", "--steps", "3",
+    for depth, edge, model in ((5, 16, "bgk"), (1, 8, "bgk"), (3, 16, "kbc")):
+        r = subprocess.run([exe, "--spawn", "1", "--rows", "160", "--cols", "256", "--steps", "3", "--model", model,
                             "--warmup", "1", "--depth", str(depth), "--edge-rows", str(edge), "--check", "1",
-                            "--id-file", str(tmp_path / f"id{depth}")],
+                            "--id-file", str(tmp_path / f"id{depth}{model}")],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
