@@ -94,7 +94,7 @@ static int launch_cg_strip_t(double* pn_r, double* pn_b, const double* in_r, con
                              const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
                              double* rho_b, double* u, double* psi, double* snu, const MacroIdx& mi,
                              int row_begin, int row_end, hipStream_t st) {
-  int rpc = tuning("cg_rows", 64);
+  int rpc = tuning("cg_rows", 16);
   const int nrows = row_end - row_begin;
   if (rpc > nrows) rpc = nrows;
   const int strips = (g.C + CG_SW - 1) / CG_SW, chunks = (nrows + rpc - 1) / rpc;

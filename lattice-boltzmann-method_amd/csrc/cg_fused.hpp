@@ -344,12 +344,12 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
 // program order).  Against the tile kernel above: ~2x less HBM read traffic (its +-3 column ring
 // costs whole 128-B lines on both sides of a 32-column tile, 299 B read per node measured).
 // Same per-node arithmetic as the tile kernel: identical bits.
-// MEASURED (8192 x 2048): 6.0-6.4 k MLUPS against the tile kernel's 12.1-12.4 k -- opt-in only
-// (tuning "cg_strip" = 1 / 2 / 4 waves per block).  As written the kernel needs 362 VGPRs (two inlined
-// copies of the gather, each with the boundary path), runs one wave per SIMD without software
-// pipelining, and a 2048-column lattice yields only 35 strips x 128 chunks = 4480 wavefronts;
-// capping it at 256 VGPRs spills (5.2 k).  The BGK sliding window got its speed from prefetching
-// the next row and from 2 waves per SIMD; the same work is open here.
+// MEASURED (8192 x 2048): 11.5 k MLUPS (4 waves per block, 16 rows per chunk) against the tile
+// kernel's 14.1 k -- opt-in (tuning "cg_strip" = 1 / 2 / 4 waves per block, "cg_rows").  History: 6.3 k
+// with two inlined copies of the gather and the stencils unrolled (362 VGPRs, 1 wave per SIMD);
+// one inlined copy (a 2-pass loop) and rolled stencil loops: 166 VGPRs, 3 waves per SIMD.  What
+// still separates it from the tile kernel: the row to collide is gathered a second time (its
+// populations are not kept across the two iterations) and nothing is prefetched.
 constexpr int CG_SW = 60;  // output columns per wavefront
 
 template <int WAVES, bool WITH_FIELDS>
@@ -409,24 +409,36 @@ __global__ __launch_bounds__(64 * WAVES) void k_cg_strip(
 
   const int n_iter = (R1 - R0) + 4;
   for (int i = 0; i < n_iter; ++i) {
-    {  // (1) macroscopic row R0 - 2 + i -> ring slot i % 5
-      int m = R0 - 2 + i;
-      m = m < rlo ? rlo : (m > rhi ? rhi : m);  // replicate padding along r (global edges only)
-      double tmp[Q];
-      const CgNode nb = node(tmp, m, cm);
-      const int slot = i % 5;
-      s_psi[slot][lane + 2] = nb.psi;
-      s_qx[slot][lane + 2] = nb.qx;
-      s_qy[slot][lane + 2] = nb.qy;
+    // two gathers per iteration through ONE inlined copy of `node`: pass 0 = the new macroscopic
+    // row R0 - 2 + i (-> ring slot i % 5), pass 1 = the row to collide, r = R0 + i - 4
+    double ft[Q];
+    CgNode me;
+    const int r = R0 + i - 4;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+      int row, col;
+      if (pass == 0) {
+        row = R0 - 2 + i;
+        row = row < rlo ? rlo : (row > rhi ? rhi : row);  // replicate padding along r (global edges only)
+        col = cm;
+      } else {
+        if (i < 4) break;
+        row = r;
+        col = lane_out ? c : cm;
+      }
+      me = node(ft, row, col);
+      if (pass == 0) {
+        const int slot = i % 5;
+        s_psi[slot][lane + 2] = me.psi;
+        s_qx[slot][lane + 2] = me.qx;
+        s_qy[slot][lane + 2] = me.qy;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (i < 4) continue;
-    const int r = R0 + i - 4;  // rows r-2 .. r+2 are in slots (i-4 .. i) % 5
     if (lane_out) {
-      double ft[Q];
-      const CgNode me = node(ft, r, c);
       // the 5 ring rows in stencil order; columns lane-2 .. lane+2 sit at [lane .. lane+4]
       const int s0 = (i - 4) % 5, s1 = (i - 3) % 5, s3 = (i - 1) % 5, s4 = i % 5;
       constexpr double k = 1.0 / 5040.0;
