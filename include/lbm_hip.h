@@ -460,6 +460,16 @@ int lbm_snapshot_record(lbm_snapshot* sn);
 int lbm_snapshot_write_npy(lbm_snapshot* sn, const char* rho_path, const char* u_path);
 /* wait for that copy; host pointers (valid until the next record) and the step they belong to */
 int lbm_snapshot_host(lbm_snapshot* sn, const double** rho, const double** u, long long* step);
+/* the same for the two-phase solver: rho_r, rho_b [R,C] and u [R,C,2] of the CURRENT state (what the
+ * driver holds after the iterations run so far); record() returns at once */
+typedef struct lbm_cg_snapshot lbm_cg_snapshot;
+int lbm_cg_snapshot_create(lbm_cg_snapshot** out, lbm_cg_solver* sv);
+int lbm_cg_snapshot_destroy(lbm_cg_snapshot* sn);
+int lbm_cg_snapshot_record(lbm_cg_snapshot* sn);
+int lbm_cg_snapshot_host(lbm_cg_snapshot* sn, const double** rho_r, const double** rho_b,
+                         const double** u, long long* step);
+int lbm_cg_snapshot_write_npy(lbm_cg_snapshot* sn, const char* rho_r_path, const char* rho_b_path,
+                              const char* u_path);
 /* raw checkpoint of the resident lattice + state form + step counter + parameters; restart is
  * bitwise.  load needs a solver of the same model and size. */
 int lbm_solver_checkpoint_save(lbm_solver* sv, const char* path);

@@ -377,3 +377,101 @@ int lbm_cg_solver_sync(lbm_cg_solver* sv) {
 }
 
 }  // extern "C"
+
+// ---- asynchronous snapshots of the two-phase solver (reference: the [R,C,n_snap] stacks written by
+// torch::save at the end of a run, mrtcg_rayleigh_taylor.cpp:481-485) ---------------------------------
+// record(): rho_r, rho_b, u of the CURRENT state (pass A on the resident post-collision lattices =
+// what the driver holds after the iterations run so far) -> device staging on the solver's stream
+// -> pinned host on a private stream; returns at once, the solver may keep stepping.
+struct lbm_cg_snapshot {
+  lbm_cg_solver* sv;
+  hipStream_t copy;
+  hipEvent_t ready, done;
+  double* d_stage;  // [rho_r | rho_b | u (AoS)] = 4 n doubles
+  double* h_stage;  // pinned host, same layout
+  long step;
+};
+
+extern "C" {
+
+int lbm_cg_snapshot_destroy(lbm_cg_snapshot* sn) {
+  if (!sn) return LBM_OK;
+  if (sn->copy) (void)hipStreamSynchronize(sn->copy);
+  if (sn->d_stage) (void)hipFree(sn->d_stage);
+  if (sn->h_stage) (void)hipHostFree(sn->h_stage);
+  if (sn->ready) (void)hipEventDestroy(sn->ready);
+  if (sn->done) (void)hipEventDestroy(sn->done);
+  if (sn->copy) (void)hipStreamDestroy(sn->copy);
+  delete sn;
+  return LBM_OK;
+}
+
+int lbm_cg_snapshot_create(lbm_cg_snapshot** out, lbm_cg_solver* sv) {
+  LBM_REQUIRE(out && sv, "lbm_cg_snapshot_create: NULL argument");
+  lbm_cg_snapshot* sn = new (std::nothrow) lbm_cg_snapshot();
+  LBM_REQUIRE(sn, "lbm_cg_snapshot_create: out of host memory");
+  *sn = lbm_cg_snapshot{sv, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+  const size_t n = (size_t)sv->g.R * sv->g.C;
+  hipError_t e = hipStreamCreateWithFlags(&sn->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&sn->ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&sn->done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc(&sn->d_stage, n * 32);
+  if (e == hipSuccess) e = hipHostMalloc(&sn->h_stage, n * 32);
+  if (e != hipSuccess) {
+    set_error("lbm_cg_snapshot_create: %s", hipGetErrorString(e));
+    lbm_cg_snapshot_destroy(sn);
+    return LBM_ERR_HIP;
+  }
+  *out = sn;
+  return LBM_OK;
+}
+
+int lbm_cg_snapshot_record(lbm_cg_snapshot* sn) {
+  LBM_REQUIRE(sn, "lbm_cg_snapshot_record: NULL snapshot");
+  lbm_cg_solver* sv = sn->sv;
+  const int R = sv->g.R, C = sv->g.C;
+  const size_t n = (size_t)R * C;
+  if (sv->post) {  // moments of the streamed state, :466-477
+    int rc = lbm_cg_stream_moments(sv->rho_r, sv->rho_b, sv->u, sv->lat[sv->cur][0], sv->lat[sv->cur][1],
+                                   &sv->g, &sv->bc, &sv->prm, sv->st);
+    if (rc) return rc;
+  }
+  LBM_CHECK_HIP(hipStreamWaitEvent(sv->st, sn->done, 0));  // previous D2H of this snapshot finished
+  LBM_CHECK_HIP(hipMemcpyAsync(sn->d_stage, sv->rho_r, n * 8, hipMemcpyDeviceToDevice, sv->st));
+  LBM_CHECK_HIP(hipMemcpyAsync(sn->d_stage + n, sv->rho_b, n * 8, hipMemcpyDeviceToDevice, sv->st));
+  int rc = lbm_soa_to_aos(sn->d_stage + 2 * n, sv->u, R, C, 2, sv->st);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipEventRecord(sn->ready, sv->st));
+  LBM_CHECK_HIP(hipStreamWaitEvent(sn->copy, sn->ready, 0));
+  LBM_CHECK_HIP(hipMemcpyAsync(sn->h_stage, sn->d_stage, n * 32, hipMemcpyDeviceToHost, sn->copy));
+  LBM_CHECK_HIP(hipEventRecord(sn->done, sn->copy));
+  sn->step = sv->steps;
+  return LBM_OK;
+}
+
+int lbm_cg_snapshot_host(lbm_cg_snapshot* sn, const double** rho_r, const double** rho_b,
+                         const double** u, long long* step) {
+  LBM_REQUIRE(sn, "lbm_cg_snapshot_host: NULL snapshot");
+  LBM_CHECK_HIP(hipStreamSynchronize(sn->copy));
+  const size_t n = (size_t)sn->sv->g.R * sn->sv->g.C;
+  if (rho_r) *rho_r = sn->h_stage;
+  if (rho_b) *rho_b = sn->h_stage + n;
+  if (u) *u = sn->h_stage + 2 * n;
+  if (step) *step = sn->step;
+  return LBM_OK;
+}
+
+int lbm_cg_snapshot_write_npy(lbm_cg_snapshot* sn, const char* rho_r_path, const char* rho_b_path,
+                              const char* u_path) {
+  LBM_REQUIRE(sn, "lbm_cg_snapshot_write_npy: NULL snapshot");
+  LBM_CHECK_HIP(hipStreamSynchronize(sn->copy));
+  const long R = sn->sv->g.R, C = sn->sv->g.C;
+  const size_t n = (size_t)R * C;
+  int rc = LBM_OK;
+  if (rho_r_path) rc = write_npy(rho_r_path, sn->h_stage, {R, C});
+  if (!rc && rho_b_path) rc = write_npy(rho_b_path, sn->h_stage + n, {R, C});
+  if (!rc && u_path) rc = write_npy(u_path, sn->h_stage + 2 * n, {R, C, 2});
+  return rc;
+}
+
+}  // extern "C"

@@ -325,7 +325,8 @@ struct lbm_snapshot {
   long step;
 };
 
-static int write_npy(const char* path, const double* data, const std::vector<long>& shape) {
+namespace lbm {
+int write_npy(const char* path, const double* data, const std::vector<long>& shape) {
   std::string dict = "{'descr': '<f8', 'fortran_order': False, 'shape': (";
   for (size_t i = 0; i < shape.size(); ++i) dict += std::to_string(shape[i]) + (shape.size() == 1 || i + 1 < shape.size() ? ", " : "");
   dict += "), }";
@@ -345,6 +346,7 @@ static int write_npy(const char* path, const double* data, const std::vector<lon
   LBM_REQUIRE(ok, "short write to %s", path);
   return LBM_OK;
 }
+}  // namespace lbm
 
 struct CheckpointHeader {
   char magic[8];  // "LBMCKPT1"

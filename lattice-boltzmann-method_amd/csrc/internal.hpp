@@ -1,6 +1,7 @@
 // Host-side plumbing shared by the C-ABI translation units: per-thread error record,
 // HIP status checks, launch-geometry helpers and the tuning table.
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -12,6 +13,8 @@ namespace lbm {
 
 void set_error(const char* fmt, ...);
 int tuning(const char* key, int dflt);
+// NumPy .npy (v1.0, little-endian f64, C order) writer shared by the snapshot objects
+int write_npy(const char* path, const double* data, const std::vector<long>& shape);
 
 #define LBM_CHECK_HIP(expr)                                                              \
   do {                                                                                   \

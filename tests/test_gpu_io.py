@@ -77,3 +77,34 @@ def test_async_snapshot_npy(lib, oracle, tmp_path):
     assert step.value == 10
     lib.snapshot_destroy(sn)
     sv.close()
+
+
+def test_two_phase_async_snapshot(lib, oracle, tmp_path):
+    """lbm_cg_snapshot_*: rho_r, rho_b, u of the current two-phase state, copied out on a private
+    stream while the solver keeps stepping; .npy files read back == get_state() at that step."""
+    import ctypes as ct
+    import pyoracle
+    R, C = 96, 64
+    po = pyoracle.cg_params(R, C)
+    s0 = oracle.cg_init(po)
+    sv = pylbm.CgSolver(lib, R, C, pylbm.cg_params())
+    sv.set_state(s0["f_r"], s0["f_b"], s0["rho_r"], s0["rho_b"], s0["u"])
+    sn = ct.c_void_p()
+    lib.cg_snapshot_create(ct.byref(sn), sv.h)
+    try:
+        sv.step(7)
+        want = sv.get_state()
+        lib.cg_snapshot_record(sn)
+        sv.step(5)                                  # keeps running while the copy is in flight
+        lib.cg_snapshot_write_npy(sn, str(tmp_path / "rr.npy").encode(), str(tmp_path / "rb.npy").encode(),
+                                  str(tmp_path / "u.npy").encode())
+        step = ct.c_longlong()
+        lib.cg_snapshot_host(sn, None, None, None, ct.byref(step))
+        assert step.value == 7
+        assert bits_equal(np.load(tmp_path / "rr.npy"), want["rho_r"])
+        assert bits_equal(np.load(tmp_path / "rb.npy"), want["rho_b"])
+        assert bits_equal(np.load(tmp_path / "u.npy"), want["u"])
+        assert not bits_equal(sv.get_state()["rho_r"], want["rho_r"])   # the solver has moved on
+    finally:
+        lib.cg_snapshot_destroy(sn)
+        sv.close()
