@@ -251,3 +251,31 @@ def test_native_ring_kbc_self_exchange(lib, oracle):
     out = torch.empty((9, R, C), dtype=torch.float64, device=d)
     lib.stream(_ptr(out), _ptr(want.contiguous()), ct.byref(flat), None, None)
     assert relerr(download_aos(lib, out), fo) < 1e-12
+
+
+def test_ulbm_poiseuille_vs_unmodified_main_snapshots(lib):
+    """The ulbm_poiseuille preset against the snapshots of the UNMODIFIED test/ulbm_poiseuille.cpp main
+    (tests/golden/upo_128.npz; 300000 iterations took ~3.5 h on one CPU core): moments after
+    100 ... 100000 iterations.  Tolerance 1e-12 up to 1000 iterations, 1e-10 after (the flow is still
+    accelerating; no chaotic growth)."""
+    g = golden("upo_128.npz")
+    s2, rin, bc = _upo_case(128, 128)
+    sv = pylbm.Solver(lib, pylbm.MODEL_KBC, 128, 128, pylbm.KbcParams(s2), bc=bc)
+    sv.set_f(np.zeros((128, 128, 9)))
+    sv.set_moments(np.ones((128, 128)), np.zeros((128, 128, 2)))
+    done = 0
+    for j, i in enumerate(g["snap_index"]):
+        n = 100 * int(i)
+        if n > 100000:
+            break
+        sv.step(n - done, record_moments=False)
+        done = n
+        f = sv.get_f()
+        m0 = f.sum(-1)
+        ux = (f[..., 1] - f[..., 3] + f[..., 5] - f[..., 6] - f[..., 7] + f[..., 8]) / m0
+        uy = (f[..., 2] - f[..., 4] + f[..., 5] + f[..., 6] - f[..., 7] - f[..., 8]) / m0
+        tol = 1e-12 if n <= 1000 else 1e-10
+        assert relerr(m0, g["rho"][..., j]) < tol, n
+        assert np.abs(ux - g["ux"][..., j]).max() < tol and np.abs(uy - g["uy"][..., j]).max() < tol, n
+    assert done == 100000
+    sv.close()

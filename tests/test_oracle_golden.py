@@ -198,3 +198,21 @@ def test_decompose_domain_loop_vs_unmodified_main(oracle):
             assert np.abs(ux - want["ux"]).max() < 1e-13, (i, blk)
             assert np.abs(got["u"][k][..., 1] - want["uy"]).max() < 1e-13, (i, blk)
             assert relerr(got["rho"][k], want["rho"]) < 1e-14, (i, blk)
+
+
+def test_ulbm_poiseuille_vs_unmodified_main(oracle):
+    """orc_upo_steps against the snapshots of the unmodified test/ulbm_poiseuille.cpp main (128 x 128,
+    300000 iterations, fixture upo_128.npz): snapshot i = kbc.m0 / kbc.m1 after 100 i iterations."""
+    g = golden("upo_128.npz")
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    rin = 3.0 * 127 * (8.0 * nu * 0.05 / (128 * 128)) + 1.0
+    state, done = None, 0
+    for j, i in enumerate(g["snap_index"][:4]):                   # t = 100, 200, 500, 1000
+        n = 100 * int(i)
+        state = oracle.upo_steps(128, 128, s2, rin, 1.0, n - done, state=state)
+        done = n
+        _, m0, m1 = state
+        assert relerr(m0, g["rho"][..., j]) < 1e-12, n                 # observed 5e-14 .. 1.5e-13
+        assert np.abs(m1[..., 0] - g["ux"][..., j]).max() < 1e-12, n
+        assert np.abs(m1[..., 1] - g["uy"][..., j]).max() < 1e-12, n
