@@ -201,6 +201,23 @@ def main():
     if world > 1:
         dist.all_reduce(mass, op=dist.ReduceOp.SUM)
 
+    # informative second figure (N = 1 only, outside the timed region): the same launch schedule
+    # with the collision in the reference's exact operation order (GPU bitwise == CPU oracle)
+    ref_order = None
+    tune_now = dict(kv.split("=") for kv in a.tune)
+    if world == 1 and use_xn and tune_now.get("bgk_fast", "1") != "0":
+        lib.set_tuning(b"bgk_fast", 0)
+        advance(2 * a.xn)
+        torch.cuda.synchronize()
+        n_ref = max(a.xn, (a.steps // 2) // a.xn * a.xn)
+        t1 = time.perf_counter()
+        advance(n_ref)
+        torch.cuda.synchronize()
+        ref_order = {"value": round(R * C * n_ref / (time.perf_counter() - t1) / 1e6, 1), "unit": "MLUPS",
+                     "steps": n_ref, "kernel": f"k_stream_collide_sw<BgkModelT<0,0>,{a.xn},4,nt>",
+                     "note": "same schedule, collision in the reference's operation order (bitwise equal to the CPU oracle)"}
+        lib.set_tuning(b"bgk_fast", int(tune_now.get("bgk_fast", "-1")))
+
     if rank == 0:
         lups = R * C * world * a.steps / dt
         steps_per_launch = a.xn if use_xn else (2 if use_x2 else 1)
@@ -247,6 +264,8 @@ def main():
                          "steps_per_launch": steps_per_launch},
             "check": {"total_mass": float(mass), "expected_mass": float(R * C * world)},
         }
+        if ref_order:
+            out["reference_order"] = ref_order
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
