@@ -179,7 +179,9 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
 /* Deeper temporal blocking: p_new = n_steps (2..6) applications of the step in one launch with
  * the register sliding-window kernel (a wavefront walks down a 64-column strip keeping the last
  * three rows of every intermediate step in registers; no LDS).  One lattice read + one write per
- * n_steps updates; bit-identical results.  Periodic or ghost-row edges (ghost = 0 or >= n_steps). */
+ * n_steps updates; results identical to n_steps single-step launches.  Edges: periodic or ghost rows
+ * (ghost = 0 or >= n_steps); on a single block also bounce-back / specular columns and bounce-back /
+ * anti-bounce-back-velocity rows (n_steps <= 5), applied inside the window at every level. */
 int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
                               const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
                               int row_begin, int row_end, lbm_stream_t s);
@@ -492,7 +494,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * "sw_rows" (rows per wavefront chunk, default 64), "sw_waves" (waves per workgroup, default 4; 2 for
  * the reassociated BGK model), "sw_xcd" (G > 0: G consecutive strip groups per XCD; measured no effect);
  * "solver_depth" (steps lbm_solver_step fuses per launch on periodic BGK blocks, default 5, 1 =
- * off).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
+ * off), "solver_depth_walls" (the same on wall-bounded blocks, default 4).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);
 int lbm_get_tuning(const char* key);
 

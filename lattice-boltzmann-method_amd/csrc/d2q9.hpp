@@ -128,6 +128,60 @@ __device__ inline void gather_bc(double (&f)[Q], const double* __restrict__ p, c
 #undef OWN
 }
 
+// The boundary fix-ups of gather_bc that only need the node's OWN post-collision populations
+// (bounce-back, specular, anti-bounce-back velocity): same order -- rows first, columns win at the
+// corners.  Used by the multi-step kernels, where levels 2..D take `own` from the register ring.
+__device__ __forceinline__ void bc_fixups_own(double (&f)[Q], const double (&own)[Q], const Geom& g,
+                                              const Bc& bc, int r, int c) {
+  const bool lo = (r == 0), hi = (r == g.R - 1);
+  if (lo && bc.row_lo == LBM_EDGE_BOUNCE_BACK) {
+    f[1] = own[3]; f[5] = own[7]; f[8] = own[6];
+  }
+  if (hi && bc.row_hi == LBM_EDGE_BOUNCE_BACK) {
+    f[3] = own[1]; f[7] = own[5]; f[6] = own[8];
+  }
+  if ((lo && bc.row_lo == LBM_EDGE_ABB_VELOCITY) || (hi && bc.row_hi == LBM_EDGE_ABB_VELOCITY)) {
+    const double uu = bc.uw_r * bc.uw_r + bc.uw_c * bc.uw_c;
+#pragma unroll
+    for (int q = 1; q < Q; ++q) {
+      const double cu = bc.uw_r * (double)icx(q) + bc.uw_c * (double)icy(q);
+      const double abb = (2.0 + 9.0 * (cu * cu) - 3.0 * uu) * wq(q);
+      f[opp(q)] = -own[q] + abb;
+    }
+  }
+  if (c == g.C - 1) {
+    if (bc.col_hi == LBM_EDGE_BOUNCE_BACK) {
+      f[4] = own[2]; f[7] = own[5]; f[8] = own[6];
+    } else if (bc.col_hi == LBM_EDGE_SPECULAR) {
+      f[4] = own[2]; f[7] = own[6]; f[8] = own[5];
+    }
+  }
+  if (c == 0) {
+    if (bc.col_lo == LBM_EDGE_BOUNCE_BACK) {
+      f[2] = own[4]; f[5] = own[7]; f[6] = own[8];
+    } else if (bc.col_lo == LBM_EDGE_SPECULAR) {
+      f[2] = own[4]; f[5] = own[8]; f[6] = own[7];
+    }
+  }
+}
+// gather_bc for the wall modes above, fully inlined (the out-of-line gather_bc would force the
+// caller's population arrays -- and with them the register ring -- into scratch memory)
+__device__ __forceinline__ void gather_walls(double (&f)[Q], const double* __restrict__ p, const Geom& g,
+                                             const Bc& bc, int r, int c) {
+  double own[Q];
+  const long o = g.at(r, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    f[q] = p[q * g.plane + g.at(wrap_row(g, r - icx(q)), wrap_col(g, c - icy(q)))];
+    own[q] = p[q * g.plane + o];
+  }
+  bc_fixups_own(f, own, g, bc, r, c);
+}
+// boundary modes the multi-step kernels can carry (no pressure rows, no same-row column copy)
+__host__ __device__ inline bool bc_is_wall(int m) {
+  return m == LBM_EDGE_BOUNCE_BACK || m == LBM_EDGE_SPECULAR || m == LBM_EDGE_ABB_VELOCITY;
+}
+
 __device__ __forceinline__ bool is_edge_node(const Geom& g, int r, int c) {
   return r == 0 || r == g.R - 1 || c == 0 || c == g.C - 1;
 }
@@ -542,12 +596,12 @@ __device__ __forceinline__ double lane_from_next(double v) {  // lane i <- lane 
 #endif
 }
 
-template <class Model, int D, int K, bool NT_STORE>
+template <class Model, int D, int K, bool NT_STORE, bool HAS_BC = false>
 __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3][Q], double (&cur)[Q],
                                              double* __restrict__ pn, const double* __restrict__ po,
                                              const Geom& g, const Model& m, int i, int rbase, int R0,
                                              int R1, int c_load, const int (&cols)[3], bool lane_ok,
-                                             int c_out) {
+                                             int c_out, const Bc& bc = Bc{}, int c_raw = 0) {
   // ---- prefetch level-1 inputs of the NEXT iteration -----------------------------------------
   double nxt[Q];
   {
@@ -565,6 +619,19 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   double f[Q], rho, ux, uy;
 #pragma unroll
   for (int q = 0; q < Q; ++q) f[q] = cur[q];
+  // HAS_BC: nodes on a wall row / wall column take the full boundary gather instead of the
+  // prefetched plain one (a few lanes per row, two rows per lattice)
+  const bool col_in = c_raw >= 0 && c_raw < g.C;
+  const bool wall_col = HAS_BC && col_in && ((c_raw == 0 && bc_is_wall(bc.col_lo)) || (c_raw == g.C - 1 && bc_is_wall(bc.col_hi)));
+  // rows: periodic ones wrap (row -1 IS row R-1 and needs its wall columns treated); beyond a wall
+  // row there is only garbage that the wall row never reads
+  const bool rows_wrap = HAS_BC && !bc_is_wall(bc.row_lo) && !bc_is_wall(bc.row_hi);
+  if (HAS_BC) {
+    int r1 = rbase + i;
+    if (rows_wrap) r1 = r1 < 0 ? r1 + g.R : (r1 >= g.R ? r1 - g.R : r1);
+    const bool wall_row = (r1 == 0 && bc_is_wall(bc.row_lo)) || (r1 == g.R - 1 && bc_is_wall(bc.row_hi));
+    if (col_in && r1 >= 0 && r1 < g.R && (wall_row || wall_col)) gather_walls(f, po, g, bc, r1, c_raw);
+  }
   m.collide(f, rho, ux, uy);
   // ---- levels 2..D -------------------------------------------------------------------------------
 #pragma unroll
@@ -581,6 +648,17 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
       if (icy(q) == 1) v = lane_from_prev(v);        // from column c-1
       else if (icy(q) == -1) v = lane_from_next(v);  // from column c+1
       f[q] = v;
+    }
+    if (HAS_BC) {  // level l's row; its own level-(l-1) populations sit in the ring's c_x = 0 slot
+      int rl = rbase + i - (l - 1);
+      if (rows_wrap) rl = rl < 0 ? rl + g.R : (rl >= g.R ? rl - g.R : rl);
+      const bool wall_row = (rl == 0 && bc_is_wall(bc.row_lo)) || (rl == g.R - 1 && bc_is_wall(bc.row_hi));
+      if (col_in && rl >= 0 && rl < g.R && (wall_row || wall_col)) {
+        double own[Q];  // element-wise copy: binding the ring row by reference keeps the ring in scratch
+#pragma unroll
+        for (int q = 0; q < Q; ++q) own[q] = ring[l - 2][(K + 2) % 3][q];
+        bc_fixups_own(f, own, g, bc, rl, c_raw);
+      }
     }
     m.collide(f, rho, ux, uy);
   }
@@ -603,10 +681,10 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
 // Register budget (ring 54*(D-1) VGPRs + prefetch 18 + working set) -> waves per SIMD the kernel
 // is compiled for: D = 2: 4, D = 3: 3, D = 4, 5: 2, deeper: 1 (only enforced for 4-wave blocks).
 __host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 : (D == 3 ? 3 : (D <= 5 ? 2 : 1)); }
-template <class Model, int D, int WAVES, bool NT_STORE>
+template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
-    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group) {
+    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}) {
   constexpr int W = 64 - 2 * (D - 1);  // valid output columns per wave
   // workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th block.  xcd_group = G > 0: consecutive
   // blocks of one XCD take G consecutive strip groups, so the 128-B lines that neighbouring strips
@@ -623,10 +701,19 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)
   const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
   // this lane's column at every level; lanes D-1 .. 63-(D-1) hold valid level-D values
   int c = strip * W - (D - 1) + lane;
+  const int c_raw = c;
   const bool lane_ok = lane >= D - 1 && lane <= 63 - (D - 1) && c < g.C;
-  c = c < 0 ? c + g.C : (c >= g.C ? c - g.C : c);
-  c = c >= g.C ? c - g.C : c;  // last strip may run more than one period past the edge
-  const int cols[3] = {wrap_col(g, c + 1), c, wrap_col(g, c - 1)};
+  // walls on the columns: no wrap -- lanes left of column 0 / right of column C-1 compute garbage
+  // that the wall nodes never read (their fix-ups replace exactly the populations coming from there)
+  const bool walled_cols = HAS_BC && (bc_is_wall(bc.col_lo) || bc_is_wall(bc.col_hi));
+  if (walled_cols) {
+    c = c < 0 ? 0 : (c > g.C - 1 ? g.C - 1 : c);
+  } else {
+    c = c < 0 ? c + g.C : (c >= g.C ? c - g.C : c);
+    c = c >= g.C ? c - g.C : c;  // last strip may run more than one period past the edge
+  }
+  const int cols[3] = {walled_cols ? (c + 1 > g.C - 1 ? g.C - 1 : c + 1) : wrap_col(g, c + 1), c,
+                       walled_cols ? (c - 1 < 0 ? 0 : c - 1) : wrap_col(g, c - 1)};
   // level 1 at iteration i computes row rbase + i; level D's row = rbase + i - (D-1); the first
   // valid level-D row (all inputs warmed up) appears at i = 2(D-1) and must be R0
   const int rbase = R0 - (D - 1);
@@ -650,9 +737,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)
     for (int q = 0; q < Q; ++q) cur[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
   }
   for (int i = 0; i < n_iter; i += 3) {
-    sw_iteration<Model, D, 0, NT_STORE>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c);
-    sw_iteration<Model, D, 1, NT_STORE>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c);
-    sw_iteration<Model, D, 2, NT_STORE>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c);
+    sw_iteration<Model, D, 0, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
+    sw_iteration<Model, D, 1, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
+    sw_iteration<Model, D, 2, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
   }
 }
 

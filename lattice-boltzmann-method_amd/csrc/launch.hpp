@@ -164,9 +164,14 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R,
               "%s: row range [%d, %d) outside [0, %d)", fn, row_begin, row_end, lg->R);
   const Bc bc = make_bc(lbc);
-  LBM_REQUIRE(!bc_needs_edge_pass(bc) && !bc.pressure_rows,
-              "%s: multi-step launches support periodic / halo edges only", fn);
-  LBM_REQUIRE(depth >= 2 && depth <= 6, "%s: %d steps per launch (supported: 2..6)", fn, depth);
+  auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || bc_is_wall(m); };
+  LBM_REQUIRE(carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) && !bc.pressure_rows,
+              "%s: multi-step launches carry periodic / halo / bounce-back / specular / velocity edges only", fn);
+  const bool walls = bc_needs_edge_pass(bc);
+  // (over slabs the outer ghost rows would need the wall nodes' own populations, which the depth-D
+  // halo does not carry: single block only)
+  LBM_REQUIRE(!walls || lg->ghost == 0, "%s: wall-carrying multi-step launches are single-block only", fn);
+  LBM_REQUIRE(depth >= 2 && depth <= (walls ? 5 : 6), "%s: %d steps per launch (supported: 2..%d)", fn, depth, walls ? 5 : 6);
   LBM_REQUIRE(lg->ghost == 0 || lg->ghost >= depth, "%s: ghost=%d rows, need 0 or >= %d", fn, lg->ghost, depth);
   LBM_REQUIRE(lg->R >= 4 * depth + 8 && lg->C >= 64, "%s: lattice %dx%d too small for %d-step launches", fn, lg->R, lg->C, depth);
   if (row_begin == row_end) return LBM_OK;
@@ -179,6 +184,22 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   const long n_waves_l = (long)strips * chunks;
   LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
   const int n_waves = (int)n_waves_l, nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
+  if (walls) {  // wall-carrying variant: one block shape per model (its default)
+    const int wv = default_waves;
+#define LBM_SWBC(DV, WV)                                                                          \
+  if (depth == DV && wv == WV) {                                                                  \
+    const dim3 grid((n_waves + WV - 1) / WV);                                                     \
+    LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc); \
+  } else
+    LBM_SWBC(2, 4) LBM_SWBC(3, 4) LBM_SWBC(4, 4) LBM_SWBC(5, 4)
+    LBM_SWBC(2, 2) LBM_SWBC(3, 2) LBM_SWBC(4, 2) LBM_SWBC(5, 2) {
+      set_error("%s: no wall-carrying sliding-window instantiation for depth=%d", fn, depth);
+      return LBM_ERR_INVALID;
+    }
+#undef LBM_SWBC
+    LBM_CHECK_LAUNCH();
+    return LBM_OK;
+  }
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \

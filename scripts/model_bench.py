@@ -132,9 +132,22 @@ def bench_cylinder(X, Y, n=30):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["bgk", "kbc", "cg", "ibm"]
+    which = sys.argv[1:] or ["bgk", "walls", "kbc", "cg", "ibm"]
     if "bgk" in which:
         bench_single(pylbm.MODEL_BGK, "BGK (solver context)", 8192, 8192, pylbm.BgkParams(1.2, 0))
+    if "walls" in which:
+        for name, rows, cols in (("channel: bounce-back columns, periodic rows", False, True),
+                                 ("closed box: bounce-back rows and columns", True, True)):
+            bc = pylbm.Bc.periodic()
+            if cols:
+                bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+            if rows:
+                bc.row_lo = bc.row_hi = pylbm.EDGE_BOUNCE_BACK
+            for depth in os.environ.get("LBM_WALL_DEPTH", "5,1").split(","):
+                lib.set_tuning(b"solver_depth", int(depth))
+                bench_single(pylbm.MODEL_BGK, "BGK %s, %s step(s) per launch" % (name, depth), 8192, 8192,
+                             pylbm.BgkParams(1.2, 0), bc=bc)
+            lib.set_tuning(b"solver_depth", -1)
     if "kbc" in which:
         for depth in os.environ.get("LBM_KBC_DEPTH", "3").split(","):
             lib.set_tuning(b"kbc_depth", int(depth))
