@@ -184,15 +184,14 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   const long n_waves_l = (long)strips * chunks;
   LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
   const int n_waves = (int)n_waves_l, nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
-  if (walls) {  // wall-carrying variant: one block shape per model (its default)
-    const int wv = default_waves;
-#define LBM_SWBC(DV, WV)                                                                          \
-  if (depth == DV && wv == WV) {                                                                  \
-    const dim3 grid((n_waves + WV - 1) / WV);                                                     \
-    LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc); \
+  if (walls) {  // wall-carrying variant: 2-wave blocks only (no register cap: 4-wave blocks, capped at
+                // 168 / 256 VGPRs, spill up to 1300 registers with the fix-ups in)
+#define LBM_SWBC(DV)                                                                              \
+  if (depth == DV) {                                                                              \
+    const dim3 grid((n_waves + 1) / 2);                                                           \
+    LBM_KLAUNCH((k_stream_collide_sw<Model, DV, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc); \
   } else
-    LBM_SWBC(2, 4) LBM_SWBC(3, 4) LBM_SWBC(4, 4) LBM_SWBC(5, 4)
-    LBM_SWBC(2, 2) LBM_SWBC(3, 2) LBM_SWBC(4, 2) LBM_SWBC(5, 2) {
+    LBM_SWBC(2) LBM_SWBC(3) LBM_SWBC(4) LBM_SWBC(5) {
       set_error("%s: no wall-carrying sliding-window instantiation for depth=%d", fn, depth);
       return LBM_ERR_INVALID;
     }
