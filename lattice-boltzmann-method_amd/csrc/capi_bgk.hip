@@ -147,7 +147,8 @@ int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom
     }
   }
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
-  return launch_stream_collide_sw(fn, p_new, p_old, g, bc, m, n_steps, row_begin, row_end, as_stream(s));
+  // runtime-mode model (body force): uncapped 2-wave blocks (the 4-wave variants spill 280-410 VGPRs)
+  return launch_stream_collide_sw(fn, p_new, p_old, g, bc, m, n_steps, row_begin, row_end, as_stream(s), 2);
 }
 
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s) {
