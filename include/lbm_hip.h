@@ -208,7 +208,8 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
                            const lbm_bc* bc, const lbm_kbc_params* prm, int row_begin,
                            int row_end, double* rho, double* u, lbm_stream_t s);
 /* n_steps = 2..4 time steps per launch (register sliding window, as lbm_bgk_stream_collide_xn) with the
- * reassociated KBC collision; periodic / halo edges only */
+ * reassociated KBC collision; periodic / halo edges, and on a single block bounce-back / specular /
+ * velocity walls with n_steps <= 3 */
 int lbm_kbc_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
                               const lbm_bc* bc, const lbm_kbc_params* prm, int n_steps,
                               int row_begin, int row_end, lbm_stream_t s);

@@ -122,8 +122,11 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R,
               "%s: row range [%d, %d) outside [0, %d)", fn, row_begin, row_end, lg->R);
   const Bc bc = make_bc(lbc);
-  LBM_REQUIRE(!bc_needs_edge_pass(bc) && !bc.pressure_rows,
-              "%s: multi-step launches support periodic / halo edges only", fn);
+  auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || bc_is_wall(m); };
+  LBM_REQUIRE(carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) && !bc.pressure_rows,
+              "%s: multi-step launches carry periodic / halo / bounce-back / specular / velocity edges only", fn);
+  const bool walls = bc_needs_edge_pass(bc);
+  LBM_REQUIRE(!walls || (lg->ghost == 0 && depth <= 3), "%s: wall-carrying launches are single-block only, 2..3 steps", fn);
   LBM_REQUIRE(lg->ghost == 0 || lg->ghost >= depth, "%s: ghost=%d rows, need 0 or >= %d", fn, lg->ghost, depth);
   LBM_REQUIRE(lg->R >= 4 * depth + 8 && lg->C >= 64, "%s: lattice %dx%d too small for %d-step launches", fn, lg->R, lg->C, depth);
   if (row_begin == row_end) return LBM_OK;
@@ -137,6 +140,12 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
   const int n_waves = (int)n_waves_l;
   const dim3 grid((n_waves + 1) / 2);
+  if (walls) {
+    if (depth == 2) LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc);
+    else LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc);
+    LBM_CHECK_LAUNCH();
+    return LBM_OK;
+  }
   switch (depth) {
     case 2: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
     case 3: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;

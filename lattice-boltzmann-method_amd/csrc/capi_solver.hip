@@ -208,8 +208,8 @@ int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host) {
 static bool solver_can_fuse_steps(const lbm_solver* sv) {
   const lbm_bc& b = sv->bc;
   // periodic edges, or the wall types the sliding window carries (bounce-back, specular, velocity)
-  const bool bgk = sv->model == LBM_MODEL_BGK;  // the KBC multi-step launcher carries periodic edges only
-  auto plain = [bgk](int m) { return m == LBM_EDGE_PERIODIC || (bgk && bc_is_wall(m)); };
+  const bool bgk = sv->model == LBM_MODEL_BGK;
+  auto plain = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
   const bool model_ok = bgk || (sv->model == LBM_MODEL_KBC && tuning("kbc_fast", 1));
   return model_ok && !sv->ibm && !b.pressure_rows && plain(b.row_lo) && plain(b.row_hi) &&
          plain(b.col_lo) && plain(b.col_hi) && sv->g.C >= 64;
@@ -223,6 +223,7 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
   const bool walled = bc_is_wall(bb.row_lo) || bc_is_wall(bb.row_hi) || bc_is_wall(bb.col_lo) || bc_is_wall(bb.col_hi);
   int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 3) : tuning("solver_depth", 5);
   if (walled && sv->model == LBM_MODEL_BGK && max_depth > tuning("solver_depth_walls", 4)) max_depth = tuning("solver_depth_walls", 4);
+  if (walled && sv->model == LBM_MODEL_KBC && max_depth > 3) max_depth = 3;
   for (int i = 0; i < n;) {
     // temporal blocking: D driver iterations in one launch (bit-identical); the iteration that
     // must record moments, and the first one on a pre-collision state, run singly
