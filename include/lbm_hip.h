@@ -135,6 +135,9 @@ typedef struct lbm_bc {
  * pack  side 1: my last `depth` rows  -> message for the NEXT slab;  side 0: my first rows -> PREVIOUS.
  * unpack side 0: message from the PREVIOUS slab -> ghost rows above row 0;  side 1: from NEXT -> below. */
 #define LBM_HALO_TWO_PHASE (-3)
+/* all 9 populations of every one of d ghost rows (9 d rows): multi-step launches on slabs whose
+ * columns are walls -- the fix-ups of a ghost-row wall node read that node's own populations */
+#define LBM_HALO_FULL(d) (100 + (d))
 int lbm_halo_rows(int depth);
 int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
                   lbm_stream_t s);
@@ -180,8 +183,9 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
  * the register sliding-window kernel (a wavefront walks down a 64-column strip keeping the last
  * three rows of every intermediate step in registers; no LDS).  One lattice read + one write per
  * n_steps updates; results identical to n_steps single-step launches.  Edges: periodic or ghost rows
- * (ghost = 0 or >= n_steps); on a single block also bounce-back / specular columns and bounce-back /
- * anti-bounce-back-velocity rows (n_steps <= 5), applied inside the window at every level. */
+ * (ghost = 0 or >= n_steps); also bounce-back / specular columns and bounce-back / anti-bounce-back-
+ * velocity rows (n_steps <= 5), applied inside the window at every level -- over slabs the ghost
+ * rows must then be complete: exchange with LBM_HALO_FULL(n_steps). */
 int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
                               const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
                               int row_begin, int row_end, lbm_stream_t s);
@@ -385,6 +389,9 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
 int lbm_ring_destroy(lbm_ring* rg);
 /* refresh the ghost rows of `lattice` (ordered after the work enqueued on `after`); asynchronous */
 int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after);
+/* same with complete ghost rows (LBM_HALO_FULL): the initial fill before multi-step launches on a
+ * slab with walls (lbm_ring_bgk_step then keeps exchanging complete rows by itself) */
+int lbm_ring_exchange_full(lbm_ring* rg, double* lattice, lbm_stream_t after);
 /* same for two lattices in one message per neighbour (both colours of the two-phase model) */
 int lbm_ring_exchange2(lbm_ring* rg, double* lattice_a, double* lattice_b, lbm_stream_t after);
 /* make `main` wait for the ring's stream */

@@ -159,7 +159,10 @@ static int halo_table(HaloTable& t, int depth_code, int side, bool sender, int R
   // row 2 at columns 0 / C-1 read populations {2,5,6} / {4,7,8} of their OWN row, so the second
   // row travels complete as well: 9 + 9 + 3 rows.
   const bool two_phase = depth_code == LBM_HALO_TWO_PHASE;
-  const int depth = two_phase ? 3 : depth_code;
+  // LBM_HALO_FULL(d): every ghost row complete -- multi-step launches on slabs whose columns are
+  // walls (the fix-ups of a ghost-row wall node read that node's own populations)
+  const bool full = depth_code >= 100;
+  const int depth = two_phase ? 3 : (full ? depth_code - 100 : depth_code);
   t.n = 0;
   for (int k = 0; k < depth; ++k) {
     short pops[9];
@@ -168,7 +171,7 @@ static int halo_table(HaloTable& t, int depth_code, int side, bool sender, int R
     // c_x = 0 and outward (k = D-2), outward only (k = D-1)   [pylbm/slab.py _halo_table]
     const bool towards_next = sender ? (side == 1) : (side == 0);
     const short* outward = towards_next ? out_next : out_prev;
-    if (k <= depth - 3 || (two_phase && k == 1)) {
+    if (full || k <= depth - 3 || (two_phase && k == 1)) {
       for (short q = 0; q < 9; ++q) pops[np++] = q;
     } else if (k == depth - 2) {
       for (int j = 0; j < 3; ++j) pops[np++] = rest[j];
@@ -195,13 +198,16 @@ using namespace lbm;
 
 extern "C" {
 
-int lbm_halo_rows(int depth) { return depth == LBM_HALO_TWO_PHASE ? 21 : (depth <= 1 ? 3 : 9 * (depth - 1)); }
+int lbm_halo_rows(int depth) {
+  if (depth >= 100) return 9 * (depth - 100);
+  return depth == LBM_HALO_TWO_PHASE ? 21 : (depth <= 1 ? 3 : 9 * (depth - 1));
+}
 
 int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
                   lbm_stream_t s) {
-  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE) && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
+  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE || (depth >= 101 && depth <= 108)) && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
   {
-    const int need = depth == LBM_HALO_TWO_PHASE ? 3 : depth;
+    const int need = depth == LBM_HALO_TWO_PHASE ? 3 : (depth >= 100 ? depth - 100 : depth);
     LBM_REQUIRE(g->ghost >= need && g->R >= need && g->R < 32000, "lbm_halo_pack: ghost=%d R=%d vs depth %d", g->ghost, g->R, need);
   }
   HaloTable t;
@@ -215,9 +221,9 @@ int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int dep
 
 int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int depth, int side,
                     lbm_stream_t s) {
-  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE) && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
+  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE || (depth >= 101 && depth <= 108)) && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
   {
-    const int need = depth == LBM_HALO_TWO_PHASE ? 3 : depth;
+    const int need = depth == LBM_HALO_TWO_PHASE ? 3 : (depth >= 100 ? depth - 100 : depth);
     LBM_REQUIRE(g->ghost >= need && g->R >= need && g->R < 32000, "lbm_halo_unpack: ghost=%d R=%d vs depth %d", g->ghost, g->R, need);
   }
   HaloTable t;

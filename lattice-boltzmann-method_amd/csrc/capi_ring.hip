@@ -132,7 +132,8 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
   if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->main_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->edge_done, hipEventDisableTiming);
   // room for the two-colour message of the two-phase step when the slab has its 3 ghost rows
-  const size_t bufsz = slab->ghost == 3 ? 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C : rg->msg;
+  size_t bufsz = (size_t)lbm_halo_rows(LBM_HALO_FULL(slab->ghost)) * slab->C;  // complete ghost rows (walls)
+  if (slab->ghost == 3 && bufsz < 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C) bufsz = 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C;
   for (double** p : {&rg->send_next, &rg->send_prev, &rg->recv_prev, &rg->recv_next})
     if (e == hipSuccess) e = hipMalloc(p, bufsz * sizeof(double));
   if (e != hipSuccess) {
@@ -166,8 +167,9 @@ int lbm_ring_destroy(lbm_ring* rg) {
 // two-phase model travels in the same message) up to date: pack, one send + one recv per neighbour
 // in one RCCL group, unpack -- all enqueued on the ring's edge stream, after the work already
 // enqueued on `after`.
-static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_stream_t after) {
-  const int G = lattice2 ? LBM_HALO_TWO_PHASE : rg->g.ghost;  // two lattices = the two colours
+static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_stream_t after, bool full = false) {
+  // two lattices = the two colours; full = complete ghost rows (multi-step launches with walls)
+  const int G = lattice2 ? LBM_HALO_TWO_PHASE : (full ? LBM_HALO_FULL(rg->g.ghost) : rg->g.ghost);
   const size_t msg = (size_t)lbm_halo_rows(G) * rg->g.C;
   if (as_stream(after) != rg->edge) {
     LBM_CHECK_HIP(hipEventRecord(rg->main_done, as_stream(after)));
@@ -210,6 +212,11 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
 int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after) {
   LBM_REQUIRE(rg && lattice, "lbm_ring_exchange: NULL argument");
   return ring_exchange(rg, lattice, nullptr, after);
+}
+
+int lbm_ring_exchange_full(lbm_ring* rg, double* lattice, lbm_stream_t after) {
+  LBM_REQUIRE(rg && lattice, "lbm_ring_exchange_full: NULL argument");
+  return ring_exchange(rg, lattice, nullptr, after, true);
 }
 
 int lbm_ring_exchange2(lbm_ring* rg, double* lattice_a, double* lattice_b, lbm_stream_t after) {
@@ -265,7 +272,7 @@ int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* s
 // model's kernel on a row range.  On return `main` has been made to wait for everything: the next
 // call may follow immediately.
 template <class Rows>
-static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows) {
+static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows, bool full = false) {
   const int R = rg->g.R;
   // edge stream starts after everything previously enqueued on main (src complete)
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
@@ -273,7 +280,7 @@ static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main,
   int rc = rows(0, edge_rows, rg->edge);
   if (!rc) rc = rows(R - edge_rows, R, rg->edge);
   if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
-  if (!rc) rc = ring_exchange(rg, dst, nullptr, rg->edge);
+  if (!rc) rc = ring_exchange(rg, dst, nullptr, rg->edge, full);
   if (rc) return rc;
   LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
   LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
@@ -294,10 +301,12 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
   if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
   if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  // walls + several steps per launch: the NEXT launch reads complete ghost rows
+  const bool full = n_steps > 1 && (bc_is_wall(b.row_lo) || bc_is_wall(b.row_hi) || bc_is_wall(b.col_lo) || bc_is_wall(b.col_hi));
   return ring_step(rg, dst, edge_rows, as_stream(main_s), [&](int r0, int r1, hipStream_t st) -> int {
     if (n_steps == 1) return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
     return lbm_bgk_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
-  });
+  }, full);
 }
 
 // KBC: the same schedule (n_steps 1, or 2..4 through the sliding window with the reassociated

@@ -625,12 +625,15 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   const bool wall_col = HAS_BC && col_in && ((c_raw == 0 && bc_is_wall(bc.col_lo)) || (c_raw == g.C - 1 && bc_is_wall(bc.col_hi)));
   // rows: periodic ones wrap (row -1 IS row R-1 and needs its wall columns treated); beyond a wall
   // row there is only garbage that the wall row never reads
-  const bool rows_wrap = HAS_BC && !bc_is_wall(bc.row_lo) && !bc_is_wall(bc.row_hi);
+  // (slabs: the ghost rows behind a HALO edge are real nodes of the neighbour, wall columns included)
+  const bool rows_wrap = HAS_BC && !g.ghost && !bc_is_wall(bc.row_lo) && !bc_is_wall(bc.row_hi);
+  const int row_min = (HAS_BC && g.ghost && bc.row_lo == LBM_EDGE_HALO) ? -g.ghost : 0;
+  const int row_max = (HAS_BC && g.ghost && bc.row_hi == LBM_EDGE_HALO) ? g.R + g.ghost - 1 : g.R - 1;
   if (HAS_BC) {
     int r1 = rbase + i;
     if (rows_wrap) r1 = r1 < 0 ? r1 + g.R : (r1 >= g.R ? r1 - g.R : r1);
     const bool wall_row = (r1 == 0 && bc_is_wall(bc.row_lo)) || (r1 == g.R - 1 && bc_is_wall(bc.row_hi));
-    if (col_in && r1 >= 0 && r1 < g.R && (wall_row || wall_col)) gather_walls(f, po, g, bc, r1, c_raw);
+    if (col_in && r1 >= row_min && r1 <= row_max && (wall_row || wall_col)) gather_walls(f, po, g, bc, r1, c_raw);
   }
   m.collide(f, rho, ux, uy);
   // ---- levels 2..D -------------------------------------------------------------------------------
@@ -653,7 +656,7 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
       int rl = rbase + i - (l - 1);
       if (rows_wrap) rl = rl < 0 ? rl + g.R : (rl >= g.R ? rl - g.R : rl);
       const bool wall_row = (rl == 0 && bc_is_wall(bc.row_lo)) || (rl == g.R - 1 && bc_is_wall(bc.row_hi));
-      if (col_in && rl >= 0 && rl < g.R && (wall_row || wall_col)) {
+      if (col_in && rl >= row_min && rl <= row_max && (wall_row || wall_col)) {
         double own[Q];  // element-wise copy: binding the ring row by reference keeps the ring in scratch
 #pragma unroll
         for (int q = 0; q < Q; ++q) own[q] = ring[l - 2][(K + 2) % 3][q];

@@ -168,9 +168,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   LBM_REQUIRE(carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) && !bc.pressure_rows,
               "%s: multi-step launches carry periodic / halo / bounce-back / specular / velocity edges only", fn);
   const bool walls = bc_needs_edge_pass(bc);
-  // (over slabs the outer ghost rows would need the wall nodes' own populations, which the depth-D
-  // halo does not carry: single block only)
-  LBM_REQUIRE(!walls || lg->ghost == 0, "%s: wall-carrying multi-step launches are single-block only", fn);
+  // (over slabs the ghost rows must then be COMPLETE: exchange with LBM_HALO_FULL(depth))
   LBM_REQUIRE(depth >= 2 && depth <= (walls ? 5 : 6), "%s: %d steps per launch (supported: 2..%d)", fn, depth, walls ? 5 : 6);
   LBM_REQUIRE(lg->ghost == 0 || lg->ghost >= depth, "%s: ghost=%d rows, need 0 or >= %d", fn, lg->ghost, depth);
   LBM_REQUIRE(lg->R >= 4 * depth + 8 && lg->C >= 64, "%s: lattice %dx%d too small for %d-step launches", fn, lg->R, lg->C, depth);

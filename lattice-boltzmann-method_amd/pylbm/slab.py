@@ -25,7 +25,7 @@ import ctypes as ct
 import torch
 import torch.distributed as dist
 
-from . import EDGE_HALO, EDGE_PERIODIC, Bc, Geom
+from . import EDGE_ABB_VELOCITY, EDGE_BOUNCE_BACK, EDGE_HALO, EDGE_PERIODIC, EDGE_SPECULAR, Bc, Geom
 
 TO_NEXT = (1, 5, 8)  # c_x = +1: leave through the last owned row
 TO_PREV = (3, 6, 7)  # c_x = -1: leave through the first owned row
@@ -60,7 +60,10 @@ class _HaloTables(dict):
         self.outward = outward
 
     def __missing__(self, depth):
-        self[depth] = _halo_table(depth, self.outward)
+        if isinstance(depth, int) and depth >= 100:   # LBM_HALO_FULL(d): all 9 populations of every row
+            self[depth] = [(ALL9, k) for k in range(depth - 100)]
+        else:
+            self[depth] = _halo_table(depth, self.outward)
         return self[depth]
 
 
@@ -147,6 +150,11 @@ class SlabRing:
         self.side = None  # lazily created side stream (GPU only)
         self.schedule = 0
         self.halo_buf = None
+        # multi-step launches on slabs with wall columns / rows: every ghost row travels complete
+        # (the fix-ups of a ghost-row wall node read that node's own populations): LBM_HALO_FULL(depth)
+        walls = any(m in (EDGE_BOUNCE_BACK, EDGE_SPECULAR, EDGE_ABB_VELOCITY)
+                    for m in (self.bc.row_lo, self.bc.row_hi, self.bc.col_lo, self.bc.col_hi))
+        self.halo_code = (100 + self.ghost) if (walls and self.ghost > 1) else self.ghost
         self.next_rank = (rank + 1) % world if (periodic or rank < world - 1) else None
         self.prev_rank = (rank - 1) % world if (periodic or rank > 0) else None
 
@@ -173,11 +181,11 @@ class SlabRing:
         if not self.ghost:
             return []
         if self.lib is None or self.dev.type != "cuda":
-            ops = halo_ops([lat], self.ghost, self.R, self.next_rank, self.prev_rank)
+            ops = halo_ops([lat], self.ghost, self.R, self.next_rank, self.prev_rank, table=self.halo_code)
             return dist.batch_isend_irecv(ops) if ops else []
         import ctypes
         from . import _ptr
-        G = self.ghost
+        G = self.halo_code
         if self.halo_buf is None:
             n = self.lib.raw.lbm_halo_rows(G) * self.C
             self.halo_buf = {k: torch.empty(n, dtype=torch.float64, device=self.dev)
@@ -202,9 +210,9 @@ class SlabRing:
         from . import _ptr
         hb, st, g, lat = self.halo_buf, self.stream_ptr(), ctypes.byref(self.geom), self._unpack_target
         if self.prev_rank is not None:
-            self.lib.halo_unpack(_ptr(lat), _ptr(hb["recv_prev"]), g, self.ghost, 0, st)
+            self.lib.halo_unpack(_ptr(lat), _ptr(hb["recv_prev"]), g, self.halo_code, 0, st)
         if self.next_rank is not None:
-            self.lib.halo_unpack(_ptr(lat), _ptr(hb["recv_next"]), g, self.ghost, 1, st)
+            self.lib.halo_unpack(_ptr(lat), _ptr(hb["recv_next"]), g, self.halo_code, 1, st)
 
     # -- state ---------------------------------------------------------------------------
     def load_precollision(self, f_soa, collide):

@@ -649,3 +649,95 @@ def test_sliding_window_carries_walls(lib, oracle, case):
                     bad = (b != src).nonzero()
                     raise AssertionError((case, R, C, D, rows, float((b - src).abs().max()), bad[:6].tolist(), int(bad.shape[0]),
                                           sorted(set(bad[:, 2].tolist()))[:12], sorted(set(bad[:, 1].tolist()))[:12], sorted(set(bad[:, 0].tolist()))))
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+def test_two_slabs_with_walls_multi_step_equal_single_block(lib, oracle, depth):
+    """Wall-bounded channel over slabs with multi-step launches: 2 slabs emulated on one GPU (chain:
+    bounce-back rows at the global ends, bounce-back columns everywhere), COMPLETE ghost rows moved
+    with lbm_halo_pack / _unpack(LBM_HALO_FULL(depth)) -- the fix-ups of a ghost-row wall node read
+    that node's own populations.  Equals the single block advanced by single-step launches."""
+    Rg, C, launches = 128, 150, 3
+    R, D = Rg // 2, depth
+    f0 = random_state(oracle, Rg, C, seed=11)
+    prm = pylbm.BgkParams(1.25, 0)
+    bc_g = pylbm.Bc.periodic()
+    bc_g.row_lo = bc_g.row_hi = bc_g.col_lo = bc_g.col_hi = pylbm.EDGE_BOUNCE_BACK
+    flat = pylbm.Geom(Rg, C, 0)
+    p0 = upload_soa(lib, f0)
+    a, b = p0.clone(), torch.empty_like(p0)
+    for _ in range(D * launches):
+        lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(flat), ct.byref(bc_g), ct.byref(prm), 0, Rg, None, None, None)
+        a, b = b, a
+    torch.cuda.synchronize()
+    want = a
+    geom = pylbm.Geom(R, C, D)
+    bcs = []
+    for s in range(2):
+        bb = pylbm.Bc.periodic()
+        bb.col_lo = bb.col_hi = pylbm.EDGE_BOUNCE_BACK
+        bb.row_lo = pylbm.EDGE_BOUNCE_BACK if s == 0 else pylbm.EDGE_HALO
+        bb.row_hi = pylbm.EDGE_HALO if s == 0 else pylbm.EDGE_BOUNCE_BACK
+        bcs.append(bb)
+    lat = [[torch.zeros((9, R + 2 * D, C), dtype=torch.float64, device=dev()) for _ in range(2)] for _ in range(2)]
+    H = 100 + D
+    msg = torch.empty(lib.raw.lbm_halo_rows(H) * C, dtype=torch.float64, device=dev())
+    assert lib.raw.lbm_halo_rows(H) == 9 * D
+
+    def halo(cur):
+        lib.halo_pack(_ptr(msg), _ptr(lat[0][cur]), ct.byref(geom), H, 1, None)
+        lib.halo_unpack(_ptr(lat[1][cur]), _ptr(msg), ct.byref(geom), H, 0, None)
+        lib.halo_pack(_ptr(msg), _ptr(lat[1][cur]), ct.byref(geom), H, 0, None)
+        lib.halo_unpack(_ptr(lat[0][cur]), _ptr(msg), ct.byref(geom), H, 1, None)
+
+    for s in range(2):
+        lat[s][0][:, D:D + R] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    cur = 0
+    for _ in range(launches):
+        for s in range(2):
+            for r0, r1 in ((0, 16), (R - 16, R), (16, R - 16)):
+                lib.bgk_stream_collide_xn(_ptr(lat[s][cur ^ 1]), _ptr(lat[s][cur]), ct.byref(geom), ct.byref(bcs[s]),
+                                          ct.byref(prm), D, r0, r1, None)
+        cur ^= 1
+        halo(cur)
+    torch.cuda.synchronize()
+    got = torch.cat([lat[0][cur][:, D:D + R], lat[1][cur][:, D:D + R]], dim=1)
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_native_ring_with_wall_columns(lib, oracle):
+    """lbm_ring_bgk_step on a channel (bounce-back columns, periodic rows): one rank, self send/recv
+    of COMPLETE ghost rows, 4-step launches; equals the single block advanced step by step."""
+    R, C, D, launches = 96, 200, 4, 3
+    f0 = random_state(oracle, R, C, seed=12)
+    prm = pylbm.BgkParams(1.2, 0)
+    bc = pylbm.Bc.periodic()
+    bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+    flat = pylbm.Geom(R, C, 0)
+    p0 = upload_soa(lib, f0)
+    a, b = p0.clone(), torch.empty_like(p0)
+    for _ in range(D * launches):
+        lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(flat), ct.byref(bc), ct.byref(prm), 0, R, None, None, None)
+        a, b = b, a
+    torch.cuda.synchronize()
+    g = pylbm.Geom(R, C, D)
+    lat = [torch.zeros((9, R + 2 * D, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+    lat[0][:, D:D + R] = p0
+    ident = (ct.c_ubyte * 128)()
+    ring = ct.c_void_p()
+    lib.ring_unique_id(ident)
+    lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
+    try:
+        torch.cuda.synchronize()
+        lib.ring_exchange_full(ring, _ptr(lat[0]), None)
+        lib.ring_join(ring, None)
+        cur = 0
+        for _ in range(launches):
+            lib.ring_bgk_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), ct.byref(bc), ct.byref(prm), D, 16, None)
+            cur ^= 1
+        torch.cuda.synchronize()
+        got = lat[cur][:, D:D + R]
+        assert torch.equal(got, a), float((got - a).abs().max())
+    finally:
+        lib.ring_destroy(ring)

@@ -185,3 +185,42 @@ def test_colour_gradient_ring_exchange_depth3(tmp_path):
                     # chain: no neighbour beyond the first / last slab -> ghost rows untouched
                     assert above == (val(rank - 1, f, q, R - 1 - k) if rank > 0 and need_above else -1.0)
                     assert below == (val(rank + 1, f, q, k) if rank < world - 1 and need_below else -1.0)
+
+
+def walls_exchange_worker(rank, world, port, R, C, depth, out_dir):
+    """depth-D chain exchange on a slab ring whose columns are walls: every ghost row complete"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pylbm import EDGE_BOUNCE_BACK, Bc
+    from pylbm.slab import SlabRing
+    bc = Bc.periodic()
+    bc.row_lo = bc.row_hi = bc.col_lo = bc.col_hi = EDGE_BOUNCE_BACK
+    ring = SlabRing(None, R, C, rank, world, torch.device("cpu"), periodic=False, bc=bc, plane_pad=0, depth=depth)
+    assert ring.halo_code == 100 + depth
+    G = ring.ghost
+    lat = ring.lat[0]
+    lat.fill_(-1.0)
+    for q in range(9):
+        for r in range(R):
+            lat[q, G + r, :] = 1000 * rank + 10 * q + r
+    for req in ring.exchange(lat):
+        req.wait()
+    np.save(os.path.join(out_dir, f"wlat{rank}.npy"), lat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_walled_ring_exchanges_complete_ghost_rows(tmp_path):
+    """Multi-step launches on slabs with walls need the wall nodes' own populations in the ghost
+    rows: SlabRing switches to the complete table (C ABI: LBM_HALO_FULL(depth)); depth 3, world 3."""
+    world, R, C, D = 3, 8, 4, 3
+    port = 29500 + (os.getpid() % 2000) + 91
+    mp.start_processes(walls_exchange_worker, args=(world, port, R, C, D, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    for rank in range(world):
+        a = np.load(tmp_path / f"wlat{rank}.npy")            # [9, R + 2D, C]
+        for q in range(9):
+            for k in range(D):
+                above, below = a[q, D - 1 - k, 0], a[q, D + R + k, 0]
+                assert above == (1000 * (rank - 1) + 10 * q + (R - 1 - k) if rank > 0 else -1.0)
+                assert below == (1000 * (rank + 1) + 10 * q + k if rank < world - 1 else -1.0)
