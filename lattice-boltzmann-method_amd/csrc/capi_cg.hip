@@ -207,6 +207,8 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
     case 2: return launch_cg_fused_t<8, 64, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 3: return launch_cg_fused_t<16, 32, 3>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 1: return launch_cg_fused_t<16, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 5: return launch_cg_fused_t<32, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    case 6: return launch_cg_fused_t<16, 64, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     default: return launch_cg_fused_t<16, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
   }
 }
