@@ -449,6 +449,13 @@ int lbm_links_destroy(lbm_links* t);
  * mode 1: factor ((((1 + 3 uw.c_q) + 4.5 (uw.c_q)^2) - 1.5 uw.uw) w_q) field[r]   (concentration inlet, :202) */
 int lbm_wall_terms(double* out, const double* u, int X, int Y, int col_a, double wa, int col_b, double wb,
                    double shift, int mode, const double* field, double factor, lbm_stream_t s);
+/* one pressure-periodic virtual row at the operator level, possibly between two blocks
+ * (test/decompose_domain.cpp:50-73; same lattice for dst and src: horizontal_poiseuille_test.cpp:25-45):
+ * coll_dst[dst_row] = (feq(rho_bc, u_src[src_row]) + coll_src[src_row]) - equi_src[src_row];
+ * u_src is the moment field [2][R][C] of the source block */
+int lbm_pressure_row(double* coll_dst, const lbm_geom* g_dst, int dst_row, const double* coll_src,
+                     const double* equi_src, const double* u_src, const lbm_geom* g_src, int src_row,
+                     double rho_bc, int incompressible, lbm_stream_t s);
 /* out = a * in + b, elementwise (the driver's "u + w_s", :124) */
 int lbm_axpb(double* out, const double* in, double a, double b, long long n, lbm_stream_t s);
 /* uniform momentum source on rows [row_begin, row_end) of a post-collision lattice

@@ -78,6 +78,26 @@ __global__ __launch_bounds__(256) void k_wall_terms(double* __restrict__ out, co
   }
 }
 
+// one pressure-periodic virtual row between two lattices (test/decompose_domain.cpp:50-73; with
+// dst == src lattice: horizontal_poiseuille_test.cpp:25-45 at the operator level):
+//   coll_dst[dst_row] = (feq(rho_bc, u_src[src_row]) + coll_src[src_row]) - equi_src[src_row]
+__global__ __launch_bounds__(256) void k_pressure_row(double* __restrict__ coll_dst, Geom gd, int dst_row,
+                                                      const double* __restrict__ coll_src,
+                                                      const double* __restrict__ equi_src,
+                                                      const double* __restrict__ u_src, Geom gs,
+                                                      int src_row, double rho_bc, int incompressible) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= gd.C) return;
+  const long Ns = (long)gs.R * gs.C, su = (long)src_row * gs.C + c;
+  const BgkModel m{1.0, incompressible, 0, 0, 0.0, 0.0, 0.0, 0.0};
+  double te[Q];
+  m.feq(te, rho_bc * 1.0, u_src[su], u_src[Ns + su]);
+  const long od = gd.at(dst_row, c), os = gs.at(src_row, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    coll_dst[q * gd.plane + od] = (te[q] + coll_src[q * gs.plane + os]) - equi_src[q * gs.plane + os];
+}
+
 __global__ __launch_bounds__(256) void k_axpb(double* __restrict__ out, const double* __restrict__ in,
                                               double a, double b, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a * in[i] + b;
@@ -247,6 +267,18 @@ int lbm_wall_terms(double* out, const double* u, int X, int Y, int col_a, double
   LBM_REQUIRE(mode == 0 || (mode == 1 && field), "lbm_wall_terms: mode %d (1 needs the per-row field)", mode);
   LBM_KLAUNCH(k_wall_terms, dim3((X + 255) / 256), dim3(256), 0, as_stream(s), out, u, X, Y, col_a, wa, col_b,
               wb, shift, mode, field, factor);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+
+int lbm_pressure_row(double* coll_dst, const lbm_geom* g_dst, int dst_row, const double* coll_src,
+                     const double* equi_src, const double* u_src, const lbm_geom* g_src, int src_row,
+                     double rho_bc, int incompressible, lbm_stream_t s) {
+  LBM_REQUIRE(coll_dst && g_dst && coll_src && equi_src && u_src && g_src, "lbm_pressure_row: NULL argument");
+  LBM_REQUIRE(g_dst->C == g_src->C && g_dst->ghost == 0 && g_src->ghost == 0, "lbm_pressure_row: blocks of equal width without ghost rows");
+  LBM_REQUIRE(dst_row >= 0 && dst_row < g_dst->R && src_row >= 0 && src_row < g_src->R, "lbm_pressure_row: row outside the block");
+  LBM_KLAUNCH(k_pressure_row, dim3((g_dst->C + 255) / 256), dim3(256), 0, as_stream(s), coll_dst, make_geom(*g_dst),
+              dst_row, coll_src, equi_src, u_src, make_geom(*g_src), src_row, rho_bc, incompressible);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }

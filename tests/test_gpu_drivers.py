@@ -197,6 +197,30 @@ def test_ulbm_poiseuille_driver_vs_oracle(tmp_path, oracle):
     assert u[64, 64, 0] > 0           # the pressure drop drives the flow along +r
 
 
+def test_decompose_domain_driver_vs_unmodified_main(tmp_path, oracle):
+    """SURVEY a18, test/decompose_domain.cpp (the halo contract's specification): two blocks glued by
+    cross-block pressure rows (lbm_pressure_row) and three populations per interface row each way
+    (lbm_links_*), operator-level collide/advect.  Against the snapshots of the unmodified main
+    (tests/golden/ddm_21x21.npz: adve_f, m_0, m_1 at the top of iterations 1, 2, 10, 100, 499), and
+    bitwise against the oracle restatement (no reassociated path at the operator level)."""
+    g = golden("ddm_21x21.npz")
+    H = W = 21
+    for k, t in enumerate(g["steps"]):
+        out = run("decompose_domain", "--T", int(t), "--dump", tmp_path / "ddm")
+        got = {}
+        for blk in "AB":
+            got["f" + blk] = np.fromfile(tmp_path / f"ddm-{blk}-f.f64").reshape(H, W, 9)
+            got["u" + blk] = np.fromfile(tmp_path / f"ddm-{blk}-u.f64").reshape(H, W, 2)
+            got["rho" + blk] = np.fromfile(tmp_path / f"ddm-{blk}-rho.f64").reshape(H, W)
+            assert relerr(got["f" + blk], g[f"{blk}_fs"][..., k]) < 1e-13
+            assert np.abs(got["u" + blk][..., 0] - g[f"{blk}_ux"][..., k]).max() < 1e-14
+            assert np.abs(got["u" + blk][..., 1] - g[f"{blk}_uy"][..., k]).max() < 1e-14
+            assert np.abs(got["rho" + blk] - g[f"{blk}_rho"][..., k]).max() < 1e-14
+        o = oracle.ddm_run(H, W, int(t), float(out["omega"]), float(out["rho_inlet"]), 1.0)
+        for key in ("fA", "fB", "uA", "uB", "rhoA", "rhoB"):
+            assert np.array_equal(got[key], o[key]), key
+
+
 @pytest.mark.parametrize("fast", [0, 1])
 def test_decompose_domain_loop_driver_vs_oracle(tmp_path, oracle, fast):
     """SURVEY 8(f) row 4, test/decompose_domain_loop.cpp: four blocks closed into a loop channel by
