@@ -506,7 +506,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * non-temporal loads, bit 1 non-temporal stores; default 3), "block" (128..1024, default 256),
  * "rows" (rows per thread 1/2/4, default 1), "grid_cap" (variants 1-2); two-step LDS kernel:
  * "tb_rows" (tile height, default 8), "tb_block" (default 512), "tb_order"; sliding-window kernel:
- * "sw_rows" (rows per wavefront chunk, default 64), "sw_waves" (waves per workgroup, default 4; 2 for
+ * "sw_rows" (rows per wavefront chunk; default: fitted per launch to the resident wave slots, 64 when the launch is many rounds deep), "sw_waves" (waves per workgroup, default 4; 2 for
  * the reassociated BGK model), "sw_xcd" (G > 0: G consecutive strip groups per XCD; measured no effect);
  * "solver_depth" (steps lbm_solver_step fuses per launch on periodic BGK blocks, default 5, 1 =
  * off), "solver_depth_walls" (the same on wall-bounded blocks, default 4).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */

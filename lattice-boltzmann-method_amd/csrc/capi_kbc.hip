@@ -132,25 +132,36 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   if (row_begin == row_end) return LBM_OK;
   const Geom g = make_geom(*lg);
   const int nrows = row_end - row_begin;
-  int rpc = tuning("sw_rows", 64);
-  if (rpc > nrows) rpc = nrows;
   const int W = 64 - 2 * (depth - 1);
-  const int strips = (g.C + W - 1) / W, chunks = (nrows + rpc - 1) / rpc;
-  const long n_waves_l = (long)strips * chunks;
-  LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
-  const int n_waves = (int)n_waves_l;
-  const dim3 grid((n_waves + 1) / 2);
+  const int strips = (g.C + W - 1) / W;
+  LBM_REQUIRE((long)strips * ((nrows + 31) / 32) < (1L << 30), "%s: lattice too large for one launch", fn);
+  // rows per wave: "sw_rows" if set, else fitted to the resident wave slots of the instance (launch.hpp)
+#define LBM_KBC_SW(...)                                                                               \
+  {                                                                                                   \
+    static long slots = -1;                                                                           \
+    int rpc = tuning("sw_rows", -1);                                                                  \
+    if (rpc <= 0) {                                                                                   \
+      if (slots < 0) slots = sw_wave_slots((const void*)k_stream_collide_sw<__VA_ARGS__>, 128);       \
+      rpc = slots > 0 ? sw_pick_rows(nrows, strips, depth, slots) : 64;                               \
+    }                                                                                                 \
+    if (rpc > nrows) rpc = nrows;                                                                     \
+    const int n_waves = strips * ((nrows + rpc - 1) / rpc);                                           \
+    LBM_KLAUNCH((k_stream_collide_sw<__VA_ARGS__>), dim3((n_waves + 1) / 2), dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, LBM_KBC_SW_TAIL); \
+  }
   if (walls) {
-    if (depth == 2) LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc);
-    else LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc);
+#define LBM_KBC_SW_TAIL 0, bc
+    if (depth == 2) LBM_KBC_SW(KbcFastModel, 2, 2, true, true)
+    else LBM_KBC_SW(KbcFastModel, 3, 2, true, true)
+#undef LBM_KBC_SW_TAIL
     LBM_CHECK_LAUNCH();
     return LBM_OK;
   }
-  switch (depth) {
-    case 2: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 2, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
-    case 3: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 3, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
-    default: LBM_KLAUNCH((k_stream_collide_sw<KbcFastModel, 4, 2, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); break;
-  }
+#define LBM_KBC_SW_TAIL tuning("sw_xcd", 0)
+  if (depth == 2) LBM_KBC_SW(KbcFastModel, 2, 2, true)
+  else if (depth == 3) LBM_KBC_SW(KbcFastModel, 3, 2, true)
+  else LBM_KBC_SW(KbcFastModel, 4, 2, true)
+#undef LBM_KBC_SW_TAIL
+#undef LBM_KBC_SW
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }

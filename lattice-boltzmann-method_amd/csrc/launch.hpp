@@ -153,6 +153,38 @@ int launch_stream_collide_x2(const char* fn, double* pn, const double* po, const
   return LBM_OK;
 }
 
+// Rows per wave of a sliding-window launch.  A wave walks `rows` output rows after 2 (D - 1) warm-up
+// rows; the launch runs in ceil(waves / resident wave slots) rounds and a partly filled last round
+// costs a whole chunk.  With thousands of waves per slot (the 8192^2 headline: measured flat from 48
+// to 160 rows) that tail is noise; at a few waves per slot (4096^2 KBC at one wave per SIMD: 4.3
+// rounds at 64 rows) it is 20 % of the launch -- so pick the chunk height that fills the last round.
+inline int sw_pick_rows(int nrows, int strips, int depth, long slots) {
+  auto cost = [&](int rows) {
+    const long waves = (long)strips * ((nrows + rows - 1) / rows);
+    const long rounds = (waves + slots - 1) / slots;
+    // few long rounds balance worse under dynamic dispatch than many short ones
+    return (double)rounds * (rows + 2 * (depth - 1)) * (1.0 + 0.25 / (double)rounds);
+  };
+  int best = nrows < 64 ? nrows : 64;
+  double best_cost = cost(best) * 0.95;  // leave the default unless the gain is worth having
+  for (int rows = 32; rows <= 160 && rows <= nrows; rows += 8) {
+    const double c = cost(rows);
+    if (c < best_cost) best = rows, best_cost = c;
+  }
+  return best;
+}
+
+inline long sw_wave_slots(const void* kernel, int block_threads) {
+  int blocks_per_cu = 0, dev = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block_threads, 0) != hipSuccess ||
+      hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || blocks_per_cu < 1 || cus < 1) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return (long)blocks_per_cu * (block_threads / 64) * cus;
+}
+
 // p_new = D steps from p_old with the register sliding-window kernel; rows [row_begin, row_end)
 template <class Model>
 int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const lbm_geom* lg,
@@ -175,17 +207,27 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   if (row_begin == row_end) return LBM_OK;
   const Geom g = make_geom(*lg);
   const int nrows = row_end - row_begin;
-  int rpc = tuning("sw_rows", 64);
-  if (rpc > nrows) rpc = nrows;
   const int W = 64 - 2 * (depth - 1);
-  const int strips = (g.C + W - 1) / W, chunks = (nrows + rpc - 1) / rpc;
-  const long n_waves_l = (long)strips * chunks;
-  LBM_REQUIRE(n_waves_l < (1L << 30), "%s: lattice too large for one launch", fn);
-  const int n_waves = (int)n_waves_l, nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
+  const int strips = (g.C + W - 1) / W;
+  LBM_REQUIRE((long)strips * ((nrows + 31) / 32) < (1L << 30), "%s: lattice too large for one launch", fn);
+  const int nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
+  int rpc = 0, n_waves = 0;
+  // sw_rows > 0: fixed chunk height; unset: chosen per kernel instance from its resident wave slots
+  auto plan = [&](const void* kernel, int block_threads, long& slots) {
+    rpc = tuning("sw_rows", -1);
+    if (rpc <= 0) {
+      if (slots < 0) slots = sw_wave_slots(kernel, block_threads);
+      rpc = slots > 0 ? sw_pick_rows(nrows, strips, depth, slots) : 64;
+    }
+    if (rpc > nrows) rpc = nrows;
+    n_waves = strips * ((nrows + rpc - 1) / rpc);
+  };
   if (walls) {  // wall-carrying variant: 2-wave blocks only (no register cap: 4-wave blocks, capped at
                 // 168 / 256 VGPRs, spill up to 1300 registers with the fix-ups in)
 #define LBM_SWBC(DV)                                                                              \
   if (depth == DV) {                                                                              \
+    static long slots = -1;                                                                       \
+    plan((const void*)k_stream_collide_sw<Model, DV, 2, true, true>, 128, slots);                 \
     const dim3 grid((n_waves + 1) / 2);                                                           \
     LBM_KLAUNCH((k_stream_collide_sw<Model, DV, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc); \
   } else
@@ -199,6 +241,8 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   }
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
+    static long slots = -1;                                                                       \
+    plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV, slots);                  \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
     if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
     else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0));   \

@@ -151,8 +151,13 @@ if __name__ == "__main__":
     if "kbc" in which:
         for depth in os.environ.get("LBM_KBC_DEPTH", "3").split(","):
             lib.set_tuning(b"kbc_depth", int(depth))
-            bench_single(pylbm.MODEL_KBC, "KBC (reassociated collision, %s step(s) per launch)" % depth, 4096, 4096,
-                         pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+            for size in os.environ.get("LBM_KBC_SIZE", "4096").split(","):
+                for rows in os.environ.get("LBM_SW_ROWS", "-1").split(","):
+                    lib.set_tuning(b"sw_rows", int(rows))
+                    bench_single(pylbm.MODEL_KBC, "KBC (reassociated collision, %s step(s) per launch%s)" % (
+                        depth, "" if int(rows) < 0 else ", %s rows per wave" % rows), int(size), int(size),
+                        pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+            lib.set_tuning(b"sw_rows", -1)
         lib.set_tuning(b"kbc_depth", -1)
         lib.set_tuning(b"kbc_fast", 0)
         bench_single(pylbm.MODEL_KBC, "KBC (reference operation order)", 4096, 4096,
