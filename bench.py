@@ -86,8 +86,8 @@ def cpu_baseline(rows=1024, cols=1024, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--rows", type=int, default=8192, help="rows PER GPU")
     ap.add_argument("--cols", type=int, default=8192)
     ap.add_argument("--omega", type=float, default=1.2)

@@ -138,10 +138,9 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   // rows per wave: "sw_rows" if set, else fitted to the resident wave slots of the instance (launch.hpp)
 #define LBM_KBC_SW(...)                                                                               \
   {                                                                                                   \
-    static long slots = -1;                                                                           \
     int rpc = tuning("sw_rows", -1);                                                                  \
     if (rpc <= 0) {                                                                                   \
-      if (slots < 0) slots = sw_wave_slots((const void*)k_stream_collide_sw<__VA_ARGS__>, 128);       \
+      const long slots = sw_wave_slots((const void*)k_stream_collide_sw<__VA_ARGS__>, 128);           \
       rpc = slots > 0 ? sw_pick_rows(nrows, strips, depth, slots) : 64;                               \
     }                                                                                                 \
     if (rpc > nrows) rpc = nrows;                                                                     \

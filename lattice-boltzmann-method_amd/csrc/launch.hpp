@@ -1,6 +1,9 @@
 // Host-side launch logic shared by the single-phase models (BGK, KBC): choose the interior
 // variant, launch it, then the edge pass that applies the boundary fix-ups.
 #pragma once
+#include <map>
+#include <mutex>
+#include <utility>
 #include "d2q9.hpp"
 #include "internal.hpp"
 
@@ -174,15 +177,27 @@ inline int sw_pick_rows(int nrows, int strips, int depth, long slots) {
   return best;
 }
 
+// resident wavefronts of one kernel instance on the current device (cached per instance and device)
 inline long sw_wave_slots(const void* kernel, int block_threads) {
-  int blocks_per_cu = 0, dev = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block_threads, 0) != hipSuccess ||
-      hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || blocks_per_cu < 1 || cus < 1) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, long> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
-  return (long)blocks_per_cu * (block_threads / 64) * cus;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({kernel, dev});
+  if (it != cache.end()) return it->second;
+  int blocks_per_cu = 0, cus = 0;
+  long slots = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, block_threads, 0) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && blocks_per_cu > 0 && cus > 0)
+    slots = (long)blocks_per_cu * (block_threads / 64) * cus;
+  else
+    (void)hipGetLastError();
+  cache[{kernel, dev}] = slots;
+  return slots;
 }
 
 // p_new = D steps from p_old with the register sliding-window kernel; rows [row_begin, row_end)
@@ -213,10 +228,10 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   const int nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
   int rpc = 0, n_waves = 0;
   // sw_rows > 0: fixed chunk height; unset: chosen per kernel instance from its resident wave slots
-  auto plan = [&](const void* kernel, int block_threads, long& slots) {
+  auto plan = [&](const void* kernel, int block_threads) {
     rpc = tuning("sw_rows", -1);
     if (rpc <= 0) {
-      if (slots < 0) slots = sw_wave_slots(kernel, block_threads);
+      const long slots = sw_wave_slots(kernel, block_threads);
       rpc = slots > 0 ? sw_pick_rows(nrows, strips, depth, slots) : 64;
     }
     if (rpc > nrows) rpc = nrows;
@@ -226,8 +241,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
                 // 168 / 256 VGPRs, spill up to 1300 registers with the fix-ups in)
 #define LBM_SWBC(DV)                                                                              \
   if (depth == DV) {                                                                              \
-    static long slots = -1;                                                                       \
-    plan((const void*)k_stream_collide_sw<Model, DV, 2, true, true>, 128, slots);                 \
+    plan((const void*)k_stream_collide_sw<Model, DV, 2, true, true>, 128);                        \
     const dim3 grid((n_waves + 1) / 2);                                                           \
     LBM_KLAUNCH((k_stream_collide_sw<Model, DV, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc); \
   } else
@@ -241,8 +255,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   }
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
-    static long slots = -1;                                                                       \
-    plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV, slots);                  \
+    plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV);                         \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
     if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
     else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0));   \

@@ -465,7 +465,7 @@ def test_two_slabs_two_step_launches_equal_single_block(lib, oracle):
 def test_sliding_window_temporal_blocking_bit_identical(lib, oracle, R, C):
     """lbm_bgk_stream_collide_xn (register sliding window, D = 2..6 steps per launch) == D single
     steps == oracle, bitwise; partial last strip (C not a multiple of the strip width), row
-    chunks that do not divide R, 1/2/4 waves per workgroup."""
+    chunks that do not divide R, 1/2/4 waves per workgroup, chunk height fixed or chosen by the launcher."""
     f0 = random_state(oracle, R, C, seed=3 * R + C)
     prm = pylbm.BgkParams(1.5, 0)
     g = pylbm.Geom(R, C, 0)
@@ -473,7 +473,8 @@ def test_sliding_window_temporal_blocking_bit_identical(lib, oracle, R, C):
     p0 = torch.empty((9, R, C), dtype=torch.float64, device=dev())
     lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(g), None, ct.byref(prm), None, None, None)
     out = torch.empty_like(p0)
-    for depth, rows, waves in [(2, 256, 4), (3, 16, 4), (4, 11, 2), (5, 32, 2), (6, 256, 4), (2, 7, 1), (4, 256, 4)]:
+    for depth, rows, waves in [(2, 256, 4), (3, 16, 4), (4, 11, 2), (5, 32, 2), (6, 256, 4), (2, 7, 1), (4, 256, 4),
+                               (5, -1, 2), (3, -1, 4)]:   # -1: rows fitted to the resident wave slots
         lib.set_tuning(b"sw_rows", rows)
         lib.set_tuning(b"sw_waves", waves)
         a, b = p0.clone(), torch.empty_like(p0)
