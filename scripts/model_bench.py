@@ -20,13 +20,24 @@ lib = pylbm.Lib()
 dev = torch.device("cuda:0")
 
 
-def timed(step, n, warm=5):
+def timed(step, n, warm=5, min_sec=0.4):
+    """seconds per step; the timed region is stretched to >= min_sec so that the clocks have ramped
+    (the headline bench gains 13 % between a 10 ms and a 400 ms region, profiles/r01_bench_steps_sweep.log)"""
     step(warm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step(n)
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n
+    dt = time.perf_counter() - t0
+    reps = int(min_sec / max(dt, 1e-6))
+    if reps > 1:
+        step(n * reps // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(n * reps)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+    return dt / n
 
 
 def report(name, R, C, dt, bytes_per_lup, extra=None):
