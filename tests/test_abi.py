@@ -94,3 +94,10 @@ def test_newer_entry_points_validate_before_touching_the_gpu():
     with pytest.raises(pylbm.LbmError, match="0 or 3 ghost rows"):
         lib.cg_step_fused(None, None, None, None, ct.byref(pylbm.Geom(16, 16, 2)), None, ct.byref(cg), 0, 16,
                           None, None, None, None, None, None)
+    with pytest.raises(pylbm.LbmError, match="NULL argument"):
+        lib.pressure_row(None, ct.byref(g), 0, None, None, None, ct.byref(g), 1, ct.c_double(1.0), 0, None)
+    one = (ct.c_double * 1)()
+    with pytest.raises(pylbm.LbmError, match="row outside the block"):
+        lib.pressure_row(one, ct.byref(g), 16, one, one, one, ct.byref(g), 1, ct.c_double(1.0), 0, None)
+    with pytest.raises(pylbm.LbmError, match="equal width"):
+        lib.pressure_row(one, ct.byref(g), 0, one, one, one, ct.byref(pylbm.Geom(16, 32, 0)), 1, ct.c_double(1.0), 0, None)
