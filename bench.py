@@ -101,7 +101,8 @@ def main():
     ap.add_argument("--xn", type=int, default=5,
                     help="D >= 2 (default 5): register sliding-window kernel, D time steps per launch; "
                          "0: fall back to --x2 / single-step launches")
-    ap.add_argument("--sw-rows", type=int, default=64, help="rows per wavefront chunk of the sliding-window kernel")
+    ap.add_argument("--sw-rows", type=int, default=-1,
+                    help="rows per wavefront chunk of the sliding-window kernel (-1: fitted by the launcher to the resident wave slots)")
     ap.add_argument("--edge-rows", type=int, default=32, help="rows at each slab end computed ahead of the halo exchange")
     ap.add_argument("--force-halo", action="store_true",
                     help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv)")

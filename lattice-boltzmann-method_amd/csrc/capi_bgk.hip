@@ -84,7 +84,7 @@ int lbm_bgk_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
   int rc = check_bgk("lbm_bgk_collide", prm);
   if (rc) return rc;
   if (use_fast_bgk(prm, bc))
-    return launch_collide_only("lbm_bgk_collide", p, f, g, bc, BgkFastModel{prm->omega}, rho, u, as_stream(s));
+    return launch_collide_only("lbm_bgk_collide", p, f, g, bc, BgkFastModel(prm->omega), rho, u, as_stream(s));
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   rc = launch_collide_only("lbm_bgk_collide", p, f, g, bc, m, rho, u, as_stream(s));
   if (rc) return rc;
@@ -102,7 +102,7 @@ int lbm_bgk_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
   int rc = check_bgk("lbm_bgk_stream_collide", prm);
   if (rc) return rc;
   if (use_fast_bgk(prm, bc))
-    return launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, BgkFastModel{prm->omega},
+    return launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, BgkFastModel(prm->omega),
                                  row_begin, row_end, rho, u, as_stream(s));
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   rc = launch_stream_collide("lbm_bgk_stream_collide", p_new, p_old, g, bc, m, row_begin, row_end,
@@ -122,7 +122,7 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
   int rc = check_bgk("lbm_bgk_stream_collide_x2", prm);
   if (rc) return rc;
   if (use_fast_bgk(prm, bc))
-    return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, BgkFastModel{prm->omega},
+    return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, BgkFastModel(prm->omega),
                                     row_begin, row_end, as_stream(s));
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   return launch_stream_collide_x2("lbm_bgk_stream_collide_x2", p_new, p_old, g, bc, m, row_begin,
@@ -138,7 +138,7 @@ int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom
   if (!prm->force_mode) {  // compile-time model: no mode branches inside the unrolled window
     const int key = (prm->incompressible ? 2 : 0) | (prm->delta_form ? 1 : 0);
     if (use_fast_bgk(prm, bc))  // leaner collision: best at one 2-wave block per SIMD pair (146.6 k vs 137 k MLUPS)
-      return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkFastModel{prm->omega}, n_steps, row_begin, row_end, as_stream(s), 2);
+      return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkFastModel(prm->omega), n_steps, row_begin, row_end, as_stream(s), 2);
     switch (key) {
       case 0: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
       case 1: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));

@@ -132,7 +132,7 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   if (row_begin == row_end) return LBM_OK;
   const Geom g = make_geom(*lg);
   const int nrows = row_end - row_begin;
-  const int W = 64 - 2 * (depth - 1);
+  const int W = sw_strip_width(depth, sw_full_strips<KbcFastModel>::value);
   const int strips = (g.C + W - 1) / W;
   LBM_REQUIRE((long)strips * ((nrows + 31) / 32) < (1L << 30), "%s: lattice too large for one launch", fn);
   // rows per wave: "sw_rows" if set, else fitted to the resident wave slots of the instance (launch.hpp)

@@ -8,6 +8,7 @@
 // reference writes it, so results agree with the CPU oracle to the last bit wherever the
 // oracle itself is order-deterministic.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include "../../include/lbm_hip.h"
@@ -295,7 +296,9 @@ struct BgkModelT {
 // FMA contraction per expression (identical in every kernel it is inlined into).  ~75 f64
 // operations per node instead of ~130; agreement with the reference order to rounding.
 struct BgkFastModel {
-  double omega;
+  double omega, keep, ow0, ow1, ow5;  // 1 - omega and omega * w_q, formed once on the host
+  __host__ __device__ explicit BgkFastModel(double om)
+      : omega(om), keep(1.0 - om), ow0(om * (4.0 / 9.0)), ow1(om * (1.0 / 9.0)), ow5(om * (1.0 / 36.0)) {}
   __device__ __forceinline__ void collide(double (&f)[Q], double& rho, double& ux, double& uy) const {
 #pragma clang fp contract(on)
     const double a = f[1] + f[3], b = f[2] + f[4], d57 = f[5] + f[7], d68 = f[6] + f[8];
@@ -306,22 +309,23 @@ struct BgkFastModel {
     ir = __builtin_fma(ir, __builtin_fma(-rho, ir, 1.0), ir);
     ux = jx * ir;
     uy = jy * ir;
-    constexpr double W0 = 4.0 / 9.0, W1 = 1.0 / 9.0, W5 = 1.0 / 36.0;
     const double us = ux + uy, ud = ux - uy;
     const double base = 1.0 - 1.5 * (ux * ux + uy * uy);
-    const double r1 = W1 * rho, r5 = W5 * rho;
+    // relaxation as (1 - omega) f + omega feq with omega folded into the weights: one add + one FMA
+    // per population instead of two adds + one FMA for f + omega (feq - f)
+    const double r1 = ow1 * rho, r5 = ow5 * rho;
     const double E1 = r1 * (base + 4.5 * ux * ux), E2 = r1 * (base + 4.5 * uy * uy);
     const double E5 = r5 * (base + 4.5 * us * us), E6 = r5 * (base + 4.5 * ud * ud);
     const double O1 = 3.0 * r1 * ux, O2 = 3.0 * r1 * uy, O5 = 3.0 * r5 * us, O8 = 3.0 * r5 * ud;
-    f[0] = f[0] + omega * ((W0 * rho) * base - f[0]);
-    f[1] = f[1] + omega * ((E1 + O1) - f[1]);
-    f[3] = f[3] + omega * ((E1 - O1) - f[3]);
-    f[2] = f[2] + omega * ((E2 + O2) - f[2]);
-    f[4] = f[4] + omega * ((E2 - O2) - f[4]);
-    f[5] = f[5] + omega * ((E5 + O5) - f[5]);
-    f[7] = f[7] + omega * ((E5 - O5) - f[7]);
-    f[8] = f[8] + omega * ((E6 + O8) - f[8]);
-    f[6] = f[6] + omega * ((E6 - O8) - f[6]);
+    f[0] = keep * f[0] + (ow0 * rho) * base;
+    f[1] = keep * f[1] + (E1 + O1);
+    f[3] = keep * f[3] + (E1 - O1);
+    f[2] = keep * f[2] + (E2 + O2);
+    f[4] = keep * f[4] + (E2 - O2);
+    f[5] = keep * f[5] + (E5 + O5);
+    f[7] = keep * f[7] + (E5 - O5);
+    f[8] = keep * f[8] + (E6 + O8);
+    f[6] = keep * f[6] + (E6 - O8);
   }
 };
 
@@ -683,12 +687,26 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
 
 // Register budget (ring 54*(D-1) VGPRs + prefetch 18 + working set) -> waves per SIMD the kernel
 // is compiled for: D = 2: 4, D = 3: 3, D = 4, 5: 2, deeper: 1 (only enforced for 4-wave blocks).
+// Valid output columns per wave: 64 - 2 (D - 1) lanes hold valid level-D values; the strip keeps the
+// largest multiple of 8 of them, so that every strip's stores start on a 64-byte boundary.  Measured
+// on the 8192^2 box: D = 4 at 58 columns 106 k MLUPS (every store row straddles two extra sectors:
+// partial writes), D = 5 at 56 columns 167 k.
+// A model whose collision keeps the launch VALU-bound (KBC: 400 lane-ops per update) declares
+// `static constexpr bool kFullStrips = true` and keeps all 64 - 2 (D - 1) columns: 7 % fewer strips
+// beat the aligned stores there (4096^2 KBC: 63.9 k against 60.3 k).
+__host__ __device__ constexpr int sw_strip_width(int D, bool full = false) {
+  return full ? 64 - 2 * (D - 1) : (64 - 2 * (D - 1)) / 8 * 8;
+}
+template <class M, class = void>
+struct sw_full_strips : std::false_type {};
+template <class M>
+struct sw_full_strips<M, std::void_t<decltype(M::kFullStrips)>> : std::bool_constant<M::kFullStrips> {};
 __host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 : (D == 3 ? 3 : (D <= 5 ? 2 : 1)); }
 template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
     int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}) {
-  constexpr int W = 64 - 2 * (D - 1);  // valid output columns per wave
+  constexpr int W = sw_strip_width(D, sw_full_strips<Model>::value);  // output columns per wave
   // workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th block.  xcd_group = G > 0: consecutive
   // blocks of one XCD take G consecutive strip groups, so the 128-B lines that neighbouring strips
   // share (a strip's 64 columns start 8 doubles before a line boundary) are fetched once per L2
@@ -705,7 +723,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)
   // this lane's column at every level; lanes D-1 .. 63-(D-1) hold valid level-D values
   int c = strip * W - (D - 1) + lane;
   const int c_raw = c;
-  const bool lane_ok = lane >= D - 1 && lane <= 63 - (D - 1) && c < g.C;
+  const bool lane_ok = lane >= D - 1 && lane < D - 1 + W && c < g.C;
   // walls on the columns: no wrap -- lanes left of column 0 / right of column C-1 compute garbage
   // that the wall nodes never read (their fix-ups replace exactly the populations coming from there)
   const bool walled_cols = HAS_BC && (bc_is_wall(bc.col_lo) || bc_is_wall(bc.col_hi));

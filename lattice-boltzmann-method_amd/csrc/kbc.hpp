@@ -144,6 +144,7 @@ struct KbcModel {
 // rounding (tests/test_gpu_kbc.py states the tolerance).
 struct KbcFastModel {
   double s2;
+  static constexpr bool kFullStrips = true;  // VALU-bound in the sliding window: d2q9.hpp sw_strip_width
 
   __device__ __forceinline__ static double rcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);

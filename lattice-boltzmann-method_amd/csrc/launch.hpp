@@ -170,7 +170,7 @@ inline int sw_pick_rows(int nrows, int strips, int depth, long slots) {
   };
   int best = nrows < 64 ? nrows : 64;
   double best_cost = cost(best) * 0.95;  // leave the default unless the gain is worth having
-  for (int rows = 32; rows <= 160 && rows <= nrows; rows += 8) {
+  for (int rows = 32; rows <= 192 && rows <= nrows; rows += 4) {
     const double c = cost(rows);
     if (c < best_cost) best = rows, best_cost = c;
   }
@@ -222,7 +222,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   if (row_begin == row_end) return LBM_OK;
   const Geom g = make_geom(*lg);
   const int nrows = row_end - row_begin;
-  const int W = 64 - 2 * (depth - 1);
+  const int W = sw_strip_width(depth, sw_full_strips<Model>::value);
   const int strips = (g.C + W - 1) / W;
   LBM_REQUIRE((long)strips * ((nrows + 31) / 32) < (1L << 30), "%s: lattice too large for one launch", fn);
   const int nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
@@ -257,7 +257,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   if (depth == DV && waves == WV) {                                                               \
     plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV);                         \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
-    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
+    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), (size_t)tuning("sw_lds", 0), st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
     else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0));   \
   } else
   LBM_SW(2, 4) LBM_SW(3, 4) LBM_SW(4, 4) LBM_SW(5, 4) LBM_SW(6, 4)
