@@ -257,7 +257,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   if (depth == DV && waves == WV) {                                                               \
     plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV);                         \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
-    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), (size_t)tuning("sw_lds", 0), st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
+    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
     else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0));   \
   } else
   LBM_SW(2, 4) LBM_SW(3, 4) LBM_SW(4, 4) LBM_SW(5, 4) LBM_SW(6, 4)
