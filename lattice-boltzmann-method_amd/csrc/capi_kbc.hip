@@ -206,7 +206,7 @@ int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
   if (rc) return rc;
   LBM_REQUIRE(!(bc && bc->pressure_rows), "lbm_kbc_collide: pressure rows need the moments of the source rows: use lbm_kbc_collide_first");
   if (tuning("kbc_fast", 1))
-    return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcFastModel{prm->s2}, rho, u, as_stream(s));
+    return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcFastModel(prm->s2), rho, u, as_stream(s));
   return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcModel{prm->s2}, rho, u, as_stream(s));
 }
 
@@ -237,7 +237,7 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
   // (tuning "kbc_fast" = 0) or the pressure rows -- which re-collide their source rows in that order
   // -- are in use
   if (tuning("kbc_fast", 1) && !(bc && bc->pressure_rows))
-    return launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcFastModel{prm->s2},
+    return launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcFastModel(prm->s2),
                                  row_begin, row_end, rho, u, as_stream(s));
   rc = launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcModel{prm->s2},
                              row_begin, row_end, rho, u, as_stream(s));
@@ -261,7 +261,7 @@ int lbm_kbc_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom
   LBM_REQUIRE(tuning("kbc_fast", 1), "lbm_kbc_stream_collide_xn: multi-step launches exist for the reassociated collision only (kbc_fast = 1)");
   LBM_REQUIRE(n_steps >= 2 && n_steps <= 4, "lbm_kbc_stream_collide_xn: %d steps per launch (supported: 2..4)", n_steps);
   return launch_stream_collide_sw_kbc("lbm_kbc_stream_collide_xn", p_new, p_old, g, bc,
-                                      KbcFastModel{prm->s2}, n_steps, row_begin, row_end, as_stream(s));
+                                      KbcFastModel(prm->s2), n_steps, row_begin, row_end, as_stream(s));
 }
 
 }  // extern "C"
