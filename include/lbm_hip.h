@@ -499,7 +499,9 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * Further keys: "kbc_depth" (steps lbm_solver_step fuses per launch for KBC, default 3), "cg_tile"
  * (0: 8x32, 1: 16x32, 2: 8x64, 3 / 4 [default]: 16x32 budgeted for 3 / 4 waves per SIMD, 5: 32x32, 6: 16x64), "cg_xcd" (0: hardware order; 1: XCD-contiguous eighths; 2 [default] / 4 / 8: groups of that many
  * column-neighbour tiles per XCD), "cg_strip" (0 [default]: LDS tile kernel; 1/2/4:
- * column-strip sliding-window kernel with that many waves per workgroup, "cg_rows" rows per chunk).
+ * column-strip sliding-window kernel with that many waves per workgroup, "cg_rows" rows per chunk),
+ * "cg_split" (1 [default]: inner tiles through the boundary-free instantiation + a frame launch;
+ * 0: one launch, every tile through the general boundary gather; same bits).
  * The environment variable LBM_TUNE="key=value,key=value" pre-loads the table (compiled drivers).
  * Launch-shape keys: "variant" (0 generic, 1 one node/thread grid-stride,
  * 2 two nodes/thread 16-B accesses, 3 [default] 2-D grid one node/thread), "nt" (bit 0

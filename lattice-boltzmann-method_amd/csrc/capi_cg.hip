@@ -81,11 +81,40 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
                              const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
                              double* rho_b, double* u, double* psi, double* snu, const MacroIdx& mi,
                              int row_begin, int row_end, hipStream_t st) {
-  const int tiles = ((row_end - row_begin + TR - 1) / TR) * ((g.C + TC - 1) / TC);
+  const int tiles_r = (row_end - row_begin + TR - 1) / TR, tiles_c = (g.C + TC - 1) / TC;
+  const int tiles = tiles_r * tiles_c;
   const int xs = tuning("cg_xcd", 2);  // pairs of column-neighbour tiles per XCD: +5 % at 4 waves per SIMD
-  if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
-  else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
+  // inner rectangle of tiles: the tile's ring rows r_base-2 .. r_base+TR+1 are plain nodes (not the
+  // wall rows of the global domain; across a seam the ghost rows count as plain), its ring columns
+  // c_base-2 .. c_base+TC+1 lie in [1, C-2] (their gathers do not wrap), and the tile is complete
+  const int lo_row = (g.ghost && bc.row_lo == LBM_EDGE_HALO) ? -2 : 1;
+  const int hi_row = (g.ghost && bc.row_hi == LBM_EDGE_HALO) ? g.R + 1 : g.R - 2;
+  CgTileRect rc{tiles_r, 0, 1, 0};
+  for (int i = 0; i < tiles_r; ++i) {
+    const int rb = row_begin + i * TR;
+    if (rb - 2 >= lo_row && rb + TR + 1 <= hi_row && rb + TR <= row_end) {
+      rc.ir0 = rc.ir0 < i ? rc.ir0 : i;
+      rc.ir1 = i + 1;
+    }
+  }
+  rc.ic1 = (g.C - 3) / TC;  // last tile column with c_base + TC + 1 <= C - 2
+  if (rc.ic1 > tiles_c) rc.ic1 = tiles_c;
+  const bool split = tuning("cg_split", 1) != 0 && rc.ir1 - rc.ir0 >= 1 && rc.ic1 - rc.ic0 >= 1;
+  if (!split) {
+    if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
+    else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
+    LBM_CHECK_LAUNCH();
+    return LBM_OK;
+  }
+  const int inner = (rc.ir1 - rc.ir0) * (rc.ic1 - rc.ic0), frame = tiles - inner;
+  if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
+  else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
   LBM_CHECK_LAUNCH();
+  if (frame > 0) {
+    if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 2>), dim3(frame), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
+    else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 2>), dim3(frame), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
+    LBM_CHECK_LAUNCH();
+  }
   return LBM_OK;
 }
 

@@ -81,10 +81,9 @@ __device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restr
   if (INTERIOR) {
     const long o = g.at(gr, gc);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      fr[q] = in_r[q * g.plane + (o - icx(q) * g.C - icy(q))];
-      ft[q] = in_b[q * g.plane + (o - icx(q) * g.C - icy(q))];
-    }
+    for (int q = 0; q < Q; ++q) fr[q] = in_r[q * g.plane + (o - icx(q) * g.C - icy(q))];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ft[q] = in_b[q * g.plane + (o - icx(q) * g.C - icy(q))];
   } else {
     gather_bc(fr, in_r, g, bc, gr, gc);
     gather_bc(ft, in_b, g, bc, gr, gc);
@@ -253,16 +252,26 @@ __device__ __forceinline__ void cg_collide_store(
   }
 }
 
-template <int TR, int TC, int WAVES, bool WITH_FIELDS>
+// The tiles of a launch split into an INNER rectangle [ir0, ir1) x [ic0, ic1) (tile coordinates) --
+// every node of the tile, of its +-2 ring and of their +-1 gathers lies inside the block or its
+// ghost rows and carries no boundary fix-up: plain offsets, no clamps, no wraps -- and the FRAME
+// around it, which keeps the general boundary gather.  MODE 0: all tiles through the general path
+// (small lattices), 1: the inner tiles, 2: the frame.  Same arithmetic per node in every mode.
+struct CgTileRect {
+  int ir0, ir1, ic0, ic1;
+};
+template <int TR, int TC, int WAVES, bool WITH_FIELDS, int MODE = 0>
 __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
     double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
     const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
     double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle) {
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle,
+    CgTileRect rect = CgTileRect{0, 0, 0, 0}) {
 #pragma clang fp contract(on)
   constexpr int NT = TR * TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
+  constexpr bool INNER = MODE == 1;
   __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
-  const int tiles_c = (g.C + TC - 1) / TC;
+  const int tiles_c = MODE == 1 ? rect.ic1 - rect.ic0 : (g.C + TC - 1) / TC;
   // XCD-aware tile order: the hardware deals consecutive workgroups round-robin over the 8 XCDs,
   // each with its own L2.  Neighbouring tiles share their +-3 ring (and, at 128-B lines, whole
   // cache lines on both sides of a 32-column tile: 2x read amplification when every XCD fetches
@@ -280,7 +289,26 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
     const int t2 = (m / G) * win + x * G + (m % G);
     if ((m / G + 1) * win <= (int)gridDim.x) tile = t2;
   }
-  const int r_base = row_begin + (tile / tiles_c) * TR, c_base = (tile % tiles_c) * TC;
+  int tile_r = tile / tiles_c, tile_c = tile % tiles_c;
+  if (MODE == 1) {
+    tile_r += rect.ir0;
+    tile_c += rect.ic0;
+  } else if (MODE == 2) {  // frame: tile rows above the rectangle, below it, then its left / right margins
+    const int top = rect.ir0 * tiles_c, tiles_r = (row_end - row_begin + TR - 1) / TR;
+    const int bottom = (tiles_r - rect.ir1) * tiles_c, margin = rect.ic0 + (tiles_c - rect.ic1);
+    if (tile < top) {
+      tile_r = tile / tiles_c;
+      tile_c = tile % tiles_c;
+    } else if (tile < top + bottom) {
+      tile_r = rect.ir1 + (tile - top) / tiles_c;
+      tile_c = (tile - top) % tiles_c;
+    } else {
+      const int t = tile - top - bottom, k = t % margin;
+      tile_r = rect.ir0 + t / margin;
+      tile_c = k < rect.ic0 ? k : rect.ic1 + (k - rect.ic0);
+    }
+  }
+  const int r_base = row_begin + tile_r * TR, c_base = tile_c * TC;
   const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
   const int tr = threadIdx.x / TC, tc = threadIdx.x % TC;
   const int r = r_base + tr, c = c_base + tc;
@@ -306,15 +334,19 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
     }
   };
   {
-    me = cg_node<false>(ft, in_r, in_b, g, bc, cf, r > rhi ? rhi : r, c > g.C - 1 ? g.C - 1 : c);
+    me = INNER ? cg_node<true>(ft, in_r, in_b, g, bc, cf, r, c)
+               : cg_node<false>(ft, in_r, in_b, g, bc, cf, r > rhi ? rhi : r, c > g.C - 1 ? g.C - 1 : c);
     for (int i = threadIdx.x; i < NH; i += NT) {
       int lr, lc;
       ring_slot(i, lr, lc);
       int gr = r_base + lr - 2, gc = c_base + lc - 2;
-      gr = gr < rlo ? rlo : (gr > rhi ? rhi : gr);
-      gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
+      if (!INNER) {
+        gr = gr < rlo ? rlo : (gr > rhi ? rhi : gr);
+        gc = gc < 0 ? 0 : (gc > g.C - 1 ? g.C - 1 : gc);
+      }
       double tmp[Q];
-      const CgNode nb = cg_node<false>(tmp, in_r, in_b, g, bc, cf, gr, gc);
+      const CgNode nb = INNER ? cg_node<true>(tmp, in_r, in_b, g, bc, cf, gr, gc)
+                              : cg_node<false>(tmp, in_r, in_b, g, bc, cf, gr, gc);
       s_psi[lr][lc] = nb.psi;
       s_qx[lr][lc] = nb.qx;
       s_qy[lr][lc] = nb.qy;
@@ -324,7 +356,7 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
   s_qx[tr + 2][tc + 2] = me.qx;
   s_qy[tr + 2][tc + 2] = me.qy;
   __syncthreads();
-  if (r >= row_end || c >= g.C) return;
+  if (!INNER && (r >= row_end || c >= g.C)) return;
 
   const double gx = cg_ddrow<LDC>(s_psi, tr, tc), gy = cg_ddcol<LDC>(s_psi, tr, tc);
   const double dxqx = cg_ddrow<LDC>(s_qx, tr, tc), dyqy = cg_ddcol<LDC>(s_qy, tr, tc);

@@ -285,7 +285,7 @@ def test_cg_fused_two_slabs_equal_single_block(lib, oracle):
 @pytest.mark.parametrize("R,C", [(64, 32), (256, 200), (130, 61)])
 def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
     """The two one-launch kernels -- LDS tile (default) and column-strip sliding window
-    (tuning cg_strip = 1 / 2 / 4) -- share the per-node arithmetic (FMA per source expression): identical
+    (tuning cg_strip = 1 / 2 / 4), the tile kernel with and without its inner / frame split (cg_split) -- share the per-node arithmetic (FMA per source expression): identical
     bits after 7 steps, including partial strips, partial chunks and the wall / copy edges."""
     import ctypes as ct
     from gpu_util import dev, upload_soa
@@ -303,9 +303,12 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                    ct.byref(flat), ct.byref(bc), ct.byref(pg), None, None, None)
     res = {}
     try:
-        for strip, rows in ((0, 64), (1, 64), (4, 24), (2, 7)):
+        # (0, 64): tile kernel split into inner tiles (plain gathers) + frame; (0, 0): every tile through
+        # the general boundary gather
+        for strip, rows in ((0, 64), (0, 0), (1, 64), (4, 24), (2, 7)):
             lib.set_tuning(b"cg_strip", strip)
-            lib.set_tuning(b"cg_rows", rows)
+            lib.set_tuning(b"cg_rows", rows if rows else 64)
+            lib.set_tuning(b"cg_split", 1 if rows else 0)
             a, b = [x.clone() for x in p], [torch.empty_like(p[0]) for _ in range(2)]
             for _ in range(7):
                 lib.cg_step_fused(_ptr(b[0]), _ptr(b[1]), _ptr(a[0]), _ptr(a[1]), ct.byref(flat), ct.byref(bc),
@@ -316,7 +319,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
     finally:
         lib.set_tuning(b"cg_strip", -1)
         lib.set_tuning(b"cg_rows", -1)
-    ref = res[(0, 64)]
+        lib.set_tuning(b"cg_split", -1)
+    ref = res[(0, 0)]
     for key, val in res.items():
         for k in range(2):
             assert torch.equal(val[k], ref[k]), (key, k, float((val[k] - ref[k]).abs().max()))
