@@ -238,8 +238,10 @@ __device__ __forceinline__ void cg_collide_store(
   const long lo = g.at(r, c);
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    pn_r[q * g.plane + lo] = (xr * tot[q] + cf.beta[0] * kap[q]) + src[q];
-    pn_b[q * g.plane + lo] = (xb * tot[q] + cf.beta[1] * kap[q]) + src[q];
+    // streaming stores: the new lattices are not read again in this launch, and the L2 they would
+    // occupy is what serves the ring re-reads of the neighbouring tiles
+    __builtin_nontemporal_store((xr * tot[q] + cf.beta[0] * kap[q]) + src[q], &pn_r[q * g.plane + lo]);
+    __builtin_nontemporal_store((xb * tot[q] + cf.beta[1] * kap[q]) + src[q], &pn_b[q * g.plane + lo]);
   }
   if (WITH_FIELDS) {
     const long o = mi.at(r, c), oo = (long)r * g.C + c;  // diagnostics carry no ghost rows
