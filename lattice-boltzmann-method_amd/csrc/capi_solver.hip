@@ -222,7 +222,7 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
   const lbm_bc& bb = sv->bc;
   const bool walled = bc_is_wall(bb.row_lo) || bc_is_wall(bb.row_hi) || bc_is_wall(bb.col_lo) || bc_is_wall(bb.col_hi);
   int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 3) : tuning("solver_depth", 5);
-  if (walled && sv->model == LBM_MODEL_BGK && max_depth > tuning("solver_depth_walls", 4)) max_depth = tuning("solver_depth_walls", 4);
+  if (walled && sv->model == LBM_MODEL_BGK && max_depth > tuning("solver_depth_walls", 5)) max_depth = tuning("solver_depth_walls", 5);
   if (walled && sv->model == LBM_MODEL_KBC && max_depth > 3) max_depth = 3;
   for (int i = 0; i < n;) {
     // temporal blocking: D driver iterations in one launch (bit-identical); the iteration that

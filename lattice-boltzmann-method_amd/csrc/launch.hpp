@@ -200,6 +200,49 @@ inline long sw_wave_slots(const void* kernel, int block_threads) {
   return slots;
 }
 
+// one rectangle (rows [r0, r1) x strips [s0, s0 + ns)) of a sliding-window launch through the 2-wave
+// instantiation with or without the wall fix-ups
+template <class Model, int DV, bool HAS_BC>
+void sw_launch_part(double* pn, const double* po, const Geom& g, const Model& m, const Bc& bc, int r0,
+                    int r1, int s0, int ns, int rows_fixed, hipStream_t st) {
+  if (r0 >= r1 || ns <= 0) return;
+  const int nrows = r1 - r0;
+  int rpc = rows_fixed > 0 ? rows_fixed : tuning("sw_rows", -1);
+  if (rpc <= 0) {
+    const long slots = sw_wave_slots((const void*)k_stream_collide_sw<Model, DV, 2, true, HAS_BC>, 128);
+    rpc = slots > 0 ? sw_pick_rows(nrows, ns, DV, slots) : 64;
+  }
+  if (rpc > nrows) rpc = nrows;
+  const int n_waves = ns * ((nrows + rpc - 1) / rpc);
+  LBM_KLAUNCH((k_stream_collide_sw<Model, DV, 2, true, HAS_BC>), dim3((n_waves + 1) / 2), dim3(128), 0, st, pn, po, g, m,
+              r0, r1, rpc, ns, n_waves, 0, bc, s0);
+}
+
+// Helper stream of the calling host thread on the current device: the few waves of a wall frame run
+// there, beside the interior launch on the caller's stream (fork / join through two events).  Lives
+// until the process ends; one per (thread, device).
+struct SwSideStream {
+  hipStream_t st = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  int dev = -1;
+};
+inline SwSideStream* sw_side_stream() {
+  static thread_local SwSideStream side[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  SwSideStream& s = side[dev];
+  if (s.dev != dev) {
+    if (hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    s.dev = dev;
+  }
+  return &s;
+}
+
 // p_new = D steps from p_old with the register sliding-window kernel; rows [row_begin, row_end)
 template <class Model>
 int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const lbm_geom* lg,
@@ -239,11 +282,40 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   };
   if (walls) {  // wall-carrying variant: 2-wave blocks only (no register cap: 4-wave blocks, capped at
                 // 168 / 256 VGPRs, spill up to 1300 registers with the fix-ups in)
+    // Walls touch few waves: a strip whose 64-lane window (outputs + the D-1 halo lanes on each side)
+    // holds no wall column, on rows at least D away from a wall row, runs the PLAIN instantiation -- same
+    // arithmetic, no fix-up code, fewer registers -- and only the frame around that rectangle (the
+    // outermost strips, 16 rows next to a wall row) goes through the wall-carrying one.  "sw_split" = 0:
+    // everything through the wall-carrying instantiation.
+    const bool col_walls = bc_is_wall(bc.col_lo) || bc_is_wall(bc.col_hi);
+    int ra = row_begin, rb = row_end, s0 = 0, s1 = strips;
+    if (bc_is_wall(bc.row_lo)) ra = row_begin > 16 ? row_begin : 16;
+    if (bc_is_wall(bc.row_hi)) rb = row_end < g.R - 16 ? row_end : g.R - 16;
+    if (col_walls) {
+      s0 = 1;
+      s1 = (g.C - W - depth) / W + 1;  // last strip with s W + W - 1 + (D - 1) <= C - 2
+      if (s1 > strips) s1 = strips;
+    }
+    const bool split = tuning("sw_split", 1) != 0 && ra < rb && s0 < s1;
 #define LBM_SWBC(DV)                                                                              \
   if (depth == DV) {                                                                              \
-    plan((const void*)k_stream_collide_sw<Model, DV, 2, true, true>, 128);                        \
-    const dim3 grid((n_waves + 1) / 2);                                                           \
-    LBM_KLAUNCH((k_stream_collide_sw<Model, DV, 2, true, true>), grid, dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, 0, bc); \
+    if (split) {                                                                                  \
+      /* frame first, on the helper stream: its waves take their slots before the interior grid */ \
+      SwSideStream* sd = sw_side_stream();                                                        \
+      hipStream_t fs = st;                                                                        \
+      if (sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->st, sd->fork, 0) == hipSuccess) fs = sd->st; \
+      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, s0, 32, fs);       \
+      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, s1, strips - s1, 32, fs); \
+      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, ra, s0, s1 - s0, 16, fs);      \
+      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, rb, row_end, s0, s1 - s0, 16, fs);        \
+      sw_launch_part<Model, DV, false>(pn, po, g, m, bc, ra, rb, s0, s1 - s0, 0, st);             \
+      if (fs != st) {                                                                             \
+        LBM_CHECK_HIP(hipEventRecord(sd->join, fs));                                              \
+        LBM_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));                                       \
+      }                                                                                           \
+    } else {                                                                                      \
+      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, strips, 0, st);    \
+    }                                                                                             \
   } else
     LBM_SWBC(2) LBM_SWBC(3) LBM_SWBC(4) LBM_SWBC(5) {
       set_error("%s: no wall-carrying sliding-window instantiation for depth=%d", fn, depth);

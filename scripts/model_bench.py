@@ -156,9 +156,11 @@ if __name__ == "__main__":
                 bc.row_lo = bc.row_hi = pylbm.EDGE_BOUNCE_BACK
             for depth in os.environ.get("LBM_WALL_DEPTH", "5,1").split(","):
                 lib.set_tuning(b"solver_depth", int(depth))
+                lib.set_tuning(b"solver_depth_walls", int(depth))
                 bench_single(pylbm.MODEL_BGK, "BGK %s, %s step(s) per launch" % (name, depth), 8192, 8192,
                              pylbm.BgkParams(1.2, 0), bc=bc)
             lib.set_tuning(b"solver_depth", -1)
+            lib.set_tuning(b"solver_depth_walls", -1)
     if "kbc" in which:
         for depth in os.environ.get("LBM_KBC_DEPTH", "3").split(","):
             lib.set_tuning(b"kbc_depth", int(depth))

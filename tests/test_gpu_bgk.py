@@ -629,7 +629,7 @@ def test_sliding_window_carries_walls(lib, oracle, case):
         bc.uw_r = 0.04
         if case == "channel_delta":
             prm = pylbm.BgkParams(1.3, 0, 1)
-    for R, C in ((96, 150), (70, 64)):
+    for R, C in ((96, 150), (70, 64), (130, 420)):
         f0 = random_state(oracle, R, C, seed=3)
         g = pylbm.Geom(R, C, 0)
         p0 = upload_soa(lib, f0)
@@ -641,8 +641,11 @@ def test_sliding_window_carries_walls(lib, oracle, case):
             for _ in range(D):
                 lib.bgk_stream_collide(_ptr(a), _ptr(src), ct.byref(g), ct.byref(bc), ct.byref(prm), 0, R, None, None, None)
                 src, a = a, src
-            for rows in (64, 24):
+            # split = 1 (default): wall-free interior through the plain instantiation, frame through the
+            # wall-carrying one on the helper stream; 0: one wall-carrying launch
+            for rows, split in ((64, 1), (24, 1), (-1, 1), (64, 0)):
                 lib.set_tuning(b"sw_rows", rows)
+                lib.set_tuning(b"sw_split", split)
                 b.zero_()
                 lib.bgk_stream_collide_xn(_ptr(b), _ptr(p0), ct.byref(g), ct.byref(bc), ct.byref(prm), D, 0, R, None)
                 torch.cuda.synchronize()
@@ -650,6 +653,8 @@ def test_sliding_window_carries_walls(lib, oracle, case):
                     bad = (b != src).nonzero()
                     raise AssertionError((case, R, C, D, rows, float((b - src).abs().max()), bad[:6].tolist(), int(bad.shape[0]),
                                           sorted(set(bad[:, 2].tolist()))[:12], sorted(set(bad[:, 1].tolist()))[:12], sorted(set(bad[:, 0].tolist()))))
+    lib.set_tuning(b"sw_rows", -1)
+    lib.set_tuning(b"sw_split", -1)
 
 
 @pytest.mark.parametrize("depth", [2, 4])
