@@ -9,6 +9,7 @@
 
 #include "d2q9.hpp"
 #include "internal.hpp"
+#include "launch.hpp"
 
 namespace lbm {
 
@@ -246,6 +247,7 @@ struct lbm_graph {
 
 int lbm_graph_begin_capture(lbm_stream_t s) {
   LBM_REQUIRE(s, "lbm_graph_begin_capture: the default stream cannot be captured; create one with lbm_stream_create");
+  (void)sw_side_stream();  // the helper stream of split launches is created outside the capture
   LBM_CHECK_HIP(hipStreamBeginCapture(as_stream(s), hipStreamCaptureModeThreadLocal));
   return LBM_OK;
 }

@@ -747,3 +747,38 @@ def test_native_ring_with_wall_columns(lib, oracle):
         assert torch.equal(got, a), float((got - a).abs().max())
     finally:
         lib.ring_destroy(ring)
+
+
+def test_wall_split_launches_replay_from_a_captured_graph(lib, oracle):
+    """The interior / frame split forks onto a helper stream and queries the occupancy of its kernels:
+    both must be legal inside a stream capture (lbm_graph_*).  Two captured 5-step launches on a closed
+    box, replayed three times == six direct launches, bit for bit."""
+    R, C, D = 96, 200, 5
+    bc = pylbm.Bc.periodic()
+    bc.col_lo = bc.col_hi = bc.row_lo = bc.row_hi = pylbm.EDGE_BOUNCE_BACK
+    prm = pylbm.BgkParams(1.3, 0)
+    g = pylbm.Geom(R, C, 0)
+    p0 = upload_soa(lib, random_state(oracle, R, C, seed=11))
+    a, b = p0.clone(), torch.empty_like(p0)
+    for _ in range(3):
+        lib.bgk_stream_collide_xn(_ptr(b), _ptr(a), ct.byref(g), ct.byref(bc), ct.byref(prm), D, 0, R, None)
+        lib.bgk_stream_collide_xn(_ptr(a), _ptr(b), ct.byref(g), ct.byref(bc), ct.byref(prm), D, 0, R, None)
+    torch.cuda.synchronize()
+    want = a.clone()
+    st = ct.c_void_p()
+    lib.stream_create(ct.byref(st))
+    graph = ct.c_void_p()
+    c, d = p0.clone(), torch.empty_like(p0)
+    torch.cuda.synchronize()
+    try:
+        lib.graph_begin_capture(st)
+        lib.bgk_stream_collide_xn(_ptr(d), _ptr(c), ct.byref(g), ct.byref(bc), ct.byref(prm), D, 0, R, st)
+        lib.bgk_stream_collide_xn(_ptr(c), _ptr(d), ct.byref(g), ct.byref(bc), ct.byref(prm), D, 0, R, st)
+        lib.graph_end_capture(st, ct.byref(graph))
+        lib.graph_launch(graph, 3, st)
+        lib.stream_sync(st)
+        assert torch.equal(c, want), float((c - want).abs().max())
+    finally:
+        if graph:
+            lib.graph_destroy(graph)
+        lib.stream_destroy(st)
