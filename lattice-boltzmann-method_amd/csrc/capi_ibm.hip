@@ -134,7 +134,9 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
                                                    const double* __restrict__ rho,
                                                    double* __restrict__ F_sum, double* __restrict__ p,
                                                    Geom g, double omega, double a, double b,
-                                                   int with_source) {
+                                                   int with_source, int* flag = nullptr, int seq = 0) {
+  // resident: tell the gate on the lattice stream (k_ibm_gate) that the rest of the step may start
+  if (flag && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   extern __shared__ double lds[];
   const int nt = d.n_touched, nm = d.n_markers, n = d.RR * d.RC;
   double* s_ux = lds;            // [nt]
@@ -248,7 +250,22 @@ __global__ __launch_bounds__(256) void k_ibm_sum(int n, const double* __restrict
 
 }  // namespace lbm
 
+namespace lbm {
+// One wave on the lattice stream that ends as soon as the forcing workgroup of step `seq` is resident
+// (or after a bounded wait).  Without it the lattice launches enqueued right behind the ROI rows fill
+// every CU first, and the forcing workgroup -- 16 waves x 128 VGPRs + 135 KB LDS: a whole CU -- starts
+// only when their grid drains (kernel trace: 204 us beside them against 82 us alone).
+__global__ __launch_bounds__(64) void k_ibm_gate(const int* flag, int seq, int budget) {
+  if (threadIdx.x != 0) return;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq && --budget > 0)
+    __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace lbm
+
 struct lbm_ibm {
+  int* flag = nullptr;  // device word: sequence number of the last forcing workgroup that became resident
+  int seq = 0;          // host count of lbm_ibm_step launches of the one-workgroup kernel
+  bool gate_ok = false; // the last lbm_ibm_step went through that kernel
   lbm::IbmDev d;
   int m_max, r1, c1;
   bool lds_opt_in = false;
@@ -358,6 +375,8 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   if (e == hipSuccess) e = hipMemset(ib->F_sum, 0, (size_t)n * 16);  // k_ibm_step writes touched nodes only
   if (e == hipSuccess) e = hipMalloc(&ib->fj, (size_t)n_markers * 16);
   if (e == hipSuccess) e = hipMalloc(&ib->out2, 16);
+  if (e == hipSuccess) e = hipMalloc(&ib->flag, sizeof(int));
+  if (e == hipSuccess) e = hipMemset(ib->flag, 0, sizeof(int));
   if (e != hipSuccess) {
     set_error("lbm_ibm_create: HIP allocation/copy failed: %s", hipGetErrorString(e));
     lbm_ibm_destroy(ib);
@@ -378,7 +397,7 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
 int lbm_ibm_destroy(lbm_ibm* ib) {
   if (!ib) return LBM_OK;
   for (void* p : {ib->dev_blob, (void*)ib->u_roi, (void*)ib->rho_roi, (void*)ib->F_sum,
-                  (void*)ib->fj, (void*)ib->out2})
+                  (void*)ib->fj, (void*)ib->out2, (void*)ib->flag})
     if (p) (void)hipFree(p);
   delete ib;
   return LBM_OK;
@@ -441,6 +460,7 @@ int lbm_ibm_step(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, con
               "lbm_ibm_step: lattice %dx%d does not match the boundary's %dx%d", g->R, g->C, ib->d.X, ib->d.Y);
   const size_t lds = ((size_t)3 * ib->d.n_touched + 2 * (size_t)ib->d.n_markers) * sizeof(double);
   if (ib->d.n_touched > 8 * 1024 || lds > 150 * 1024) {  // large boundaries: the launch chain
+    ib->gate_ok = false;
     int rc = lbm_ibm_force(ib, u, rho, nullptr, s);
     if (!rc) rc = lbm_ibm_add_source(ib, p, g, u, omega, a, b, s);
     return rc;
@@ -450,11 +470,24 @@ int lbm_ibm_step(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, con
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     ib->lds_opt_in = true;
   }
+  ++ib->seq;
+  ib->gate_ok = true;
   LBM_KLAUNCH(k_ibm_step, dim3(1), dim3(1024), lds, as_stream(s), ib->d, ib->m_max, u, rho, ib->F_sum, p,
-              make_geom(*g), omega, a, b, 1);
+              make_geom(*g), omega, a, b, 1, ib->flag, ib->seq);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
+
+}  // extern "C"
+namespace lbm {
+int ibm_gate(lbm_ibm* ib, hipStream_t st) {
+  if (!ib || !ib->gate_ok || tuning("ibm_gate", 1) == 0) return LBM_OK;
+  LBM_KLAUNCH(k_ibm_gate, dim3(1), dim3(64), 0, st, ib->flag, ib->seq, 4000);  // <= ~4 ms, then gives up
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+}  // namespace lbm
+extern "C" {
 
 int lbm_ibm_surface_force(lbm_ibm* ib, double* out2, lbm_stream_t s) {
   LBM_REQUIRE(ib && out2, "lbm_ibm_surface_force: NULL argument");

@@ -62,6 +62,8 @@ static int solver_fused(lbm_solver* sv, double* rho, double* u, bool with_ibm_ov
     rc = lbm_ibm_step(sv->ibm, dst, &sv->g, u, rho, sv->bgk.omega, sv->guo_a, sv->guo_b, sv->side);
     if (rc) return rc;
     LBM_CHECK_HIP(hipEventRecord(sv->ev_ibm, sv->side));
+    rc = ibm_gate(sv->ibm, sv->st);  // the lattice launches below must not take the forcing workgroup's CU first
+    if (rc) return rc;
     rc = lbm_bgk_stream_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, q1, sv->g.R, nullptr, nullptr, sv->st);
     if (!rc) rc = lbm_bgk_stream_collide(dst, src, &sv->g, &sv->bc, &sv->bgk, 0, q0, nullptr, nullptr, sv->st);
     if (rc) return rc;

@@ -13,6 +13,8 @@ namespace lbm {
 
 void set_error(const char* fmt, ...);
 int tuning(const char* key, int dflt);
+// capi_ibm.hip: one-wave kernel on `st` that ends once the last lbm_ibm_step's workgroup is resident
+int ibm_gate(lbm_ibm* ib, hipStream_t st);
 // NumPy .npy (v1.0, little-endian f64, C order) writer shared by the snapshot objects
 int write_npy(const char* path, const double* data, const std::vector<long>& shape);
 
