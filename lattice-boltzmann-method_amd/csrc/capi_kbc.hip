@@ -147,11 +147,10 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
     const int n_waves = strips * ((nrows + rpc - 1) / rpc);                                           \
     LBM_KLAUNCH((k_stream_collide_sw<__VA_ARGS__>), dim3((n_waves + 1) / 2), dim3(128), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, LBM_KBC_SW_TAIL); \
   }
-  if (walls) {
-#define LBM_KBC_SW_TAIL 0, bc
-    if (depth == 2) LBM_KBC_SW(KbcFastModel, 2, 2, true, true)
-    else LBM_KBC_SW(KbcFastModel, 3, 2, true, true)
-#undef LBM_KBC_SW_TAIL
+  if (walls) {  // plain instantiation on the wall-free interior, wall-carrying one on the frame (launch.hpp)
+    rc = depth == 2 ? sw_launch_walls<KbcFastModel, 2>(pn, po, g, m, bc, row_begin, row_end, st)
+                    : sw_launch_walls<KbcFastModel, 3>(pn, po, g, m, bc, row_begin, row_end, st);
+    if (rc) return rc;
     LBM_CHECK_LAUNCH();
     return LBM_OK;
   }

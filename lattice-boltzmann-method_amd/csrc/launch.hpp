@@ -243,6 +243,45 @@ inline SwSideStream* sw_side_stream() {
   return &s;
 }
 
+// Wall-bounded multi-step launch.  Walls touch few waves: a strip whose 64-lane window (outputs + the
+// D-1 halo lanes on each side) holds no wall column, on rows at least D away from a wall row, runs the
+// PLAIN instantiation -- same arithmetic, no fix-up code, fewer registers -- and only the frame around
+// that rectangle (the outermost strips, 16 rows next to a wall row) goes through the wall-carrying one,
+// enqueued first and on the helper stream so that its waves hold their slots while the interior grid
+// fills the rest.  "sw_split" = 0: everything through the wall-carrying instantiation.
+template <class Model, int DV>
+int sw_launch_walls(double* pn, const double* po, const Geom& g, const Model& m, const Bc& bc,
+                    int row_begin, int row_end, hipStream_t st) {
+  constexpr int W = sw_strip_width(DV, sw_full_strips<Model>::value);
+  const int strips = (g.C + W - 1) / W;
+  const bool col_walls = bc_is_wall(bc.col_lo) || bc_is_wall(bc.col_hi);
+  int ra = row_begin, rb = row_end, s0 = 0, s1 = strips;
+  if (bc_is_wall(bc.row_lo)) ra = row_begin > 16 ? row_begin : 16;
+  if (bc_is_wall(bc.row_hi)) rb = row_end < g.R - 16 ? row_end : g.R - 16;
+  if (col_walls) {
+    s0 = 1;
+    s1 = (g.C - W - DV) / W + 1;  // last strip with s W + W - 1 + (D - 1) <= C - 2
+    if (s1 > strips) s1 = strips;
+  }
+  if (tuning("sw_split", 1) == 0 || ra >= rb || s0 >= s1) {
+    sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, strips, 0, st);
+    return LBM_OK;
+  }
+  SwSideStream* sd = sw_side_stream();
+  hipStream_t fs = st;
+  if (sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->st, sd->fork, 0) == hipSuccess) fs = sd->st;
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, s0, 32, fs);
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, s1, strips - s1, 32, fs);
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, ra, s0, s1 - s0, 16, fs);
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, rb, row_end, s0, s1 - s0, 16, fs);
+  sw_launch_part<Model, DV, false>(pn, po, g, m, bc, ra, rb, s0, s1 - s0, 0, st);
+  if (fs != st) {
+    LBM_CHECK_HIP(hipEventRecord(sd->join, fs));
+    LBM_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
+  }
+  return LBM_OK;
+}
+
 // p_new = D steps from p_old with the register sliding-window kernel; rows [row_begin, row_end)
 template <class Model>
 int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const lbm_geom* lg,
@@ -282,40 +321,10 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   };
   if (walls) {  // wall-carrying variant: 2-wave blocks only (no register cap: 4-wave blocks, capped at
                 // 168 / 256 VGPRs, spill up to 1300 registers with the fix-ups in)
-    // Walls touch few waves: a strip whose 64-lane window (outputs + the D-1 halo lanes on each side)
-    // holds no wall column, on rows at least D away from a wall row, runs the PLAIN instantiation -- same
-    // arithmetic, no fix-up code, fewer registers -- and only the frame around that rectangle (the
-    // outermost strips, 16 rows next to a wall row) goes through the wall-carrying one.  "sw_split" = 0:
-    // everything through the wall-carrying instantiation.
-    const bool col_walls = bc_is_wall(bc.col_lo) || bc_is_wall(bc.col_hi);
-    int ra = row_begin, rb = row_end, s0 = 0, s1 = strips;
-    if (bc_is_wall(bc.row_lo)) ra = row_begin > 16 ? row_begin : 16;
-    if (bc_is_wall(bc.row_hi)) rb = row_end < g.R - 16 ? row_end : g.R - 16;
-    if (col_walls) {
-      s0 = 1;
-      s1 = (g.C - W - depth) / W + 1;  // last strip with s W + W - 1 + (D - 1) <= C - 2
-      if (s1 > strips) s1 = strips;
-    }
-    const bool split = tuning("sw_split", 1) != 0 && ra < rb && s0 < s1;
 #define LBM_SWBC(DV)                                                                              \
   if (depth == DV) {                                                                              \
-    if (split) {                                                                                  \
-      /* frame first, on the helper stream: its waves take their slots before the interior grid */ \
-      SwSideStream* sd = sw_side_stream();                                                        \
-      hipStream_t fs = st;                                                                        \
-      if (sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->st, sd->fork, 0) == hipSuccess) fs = sd->st; \
-      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, s0, 32, fs);       \
-      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, s1, strips - s1, 32, fs); \
-      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, ra, s0, s1 - s0, 16, fs);      \
-      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, rb, row_end, s0, s1 - s0, 16, fs);        \
-      sw_launch_part<Model, DV, false>(pn, po, g, m, bc, ra, rb, s0, s1 - s0, 0, st);             \
-      if (fs != st) {                                                                             \
-        LBM_CHECK_HIP(hipEventRecord(sd->join, fs));                                              \
-        LBM_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));                                       \
-      }                                                                                           \
-    } else {                                                                                      \
-      sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, strips, 0, st);    \
-    }                                                                                             \
+    rc = sw_launch_walls<Model, DV>(pn, po, g, m, bc, row_begin, row_end, st);                    \
+    if (rc) return rc;                                                                            \
   } else
     LBM_SWBC(2) LBM_SWBC(3) LBM_SWBC(4) LBM_SWBC(5) {
       set_error("%s: no wall-carrying sliding-window instantiation for depth=%d", fn, depth);
