@@ -30,6 +30,7 @@ struct lbm_solver {
   bool given_moments = false;  // first iteration collides on sv->rho / sv->u as set by the caller
   hipStream_t side = nullptr;  // forcing chain of the immersed boundary, beside the lattice update
   hipEvent_t ev_roi = nullptr, ev_ibm = nullptr;
+  double* band = nullptr;      // third lattice: odd / even steps of the forced band (solver_ibm_block)
 };
 
 using namespace lbm;
@@ -122,7 +123,7 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
 
 int lbm_solver_destroy(lbm_solver* sv) {
   if (!sv) return LBM_OK;
-  for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u})
+  for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u, sv->band})
     if (p) (void)hipFree(p);
   if (sv->side) {
     (void)hipStreamSynchronize(sv->side);
@@ -206,6 +207,47 @@ int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host) {
   return LBM_OK;
 }
 
+// D steps of a block with an immersed boundary.  The forcing changes every step, but only inside the
+// ROI rows [q0, q1): rows at least D away from them see plain BGK for D steps and take the multi-step
+// window (two launches, rows above / below), while a band around the ROI advances D single forced steps
+// on a trapezoid that loses one row per side and step -- step k computes rows [q0 - 2D + k, q1 + 2D - k)
+// from step k-1, so that after D steps rows [q0 - D, q1 + D) are valid and everything the band ever
+// read outside itself came from the time-t lattice.  The band alternates between lat[other] and a third
+// lattice, ending in lat[other]; the far launches come LAST (they read the time-t lattice only and
+// overwrite the rows the wider early band steps left behind).  Same kernels per node as D single steps:
+// same bits.  Returns 1 if the block does not qualify (caller falls back to single steps).
+static int solver_ibm_block(lbm_solver* sv, int D) {
+  int q0, q1, c0, c1;
+  int rc = lbm_ibm_roi(sv->ibm, &q0, &q1, &c0, &c1);
+  if (rc) return rc;
+  const int R = sv->g.R;
+  if (D < 2 || q0 - 2 * D < 2 || q1 + 2 * D > R - 2 || R < 4 * D + 8 || sv->g.C < 64) return 1;
+  if (!sv->band) {
+    const size_t bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
+    LBM_CHECK_HIP(hipMalloc(&sv->band, bytes));
+    LBM_CHECK_HIP(hipMemsetAsync(sv->band, 0, bytes, sv->st));
+  }
+  const double* src = sv->lat[sv->cur];
+  double* dst = sv->lat[sv->cur ^ 1];
+  const double* in = src;
+  for (int k = 1; k <= D; ++k) {
+    double* out = ((D - k) % 2 == 0) ? dst : sv->band;
+    const int lo = q0 - 2 * D + k, hi = q1 + 2 * D - k;
+    rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, q0, q1, sv->rho, sv->u, sv->st);
+    if (rc) return rc;
+    // one stream: beside the forcing workgroup there are only the few rows of the band to run, and a
+    // cross-stream dependency costs more than they take
+    rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, lo, q0, nullptr, nullptr, sv->st);
+    if (!rc) rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, q1, hi, nullptr, nullptr, sv->st);
+    if (!rc) rc = lbm_ibm_step(sv->ibm, out, &sv->g, sv->u, sv->rho, sv->bgk.omega, sv->guo_a, sv->guo_b, sv->st);
+    if (rc) return rc;
+    in = out;
+  }
+  rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, 0, q0 - D, sv->st);
+  if (!rc) rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, q1 + D, R, sv->st);
+  return rc;
+}
+
 // periodic or wall-bounded block without per-step observers: steps can be fused several per launch
 static bool solver_can_fuse_steps(const lbm_solver* sv) {
   const lbm_bc& b = sv->bc;
@@ -244,6 +286,18 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
       sv->steps += depth;
       i += depth;
       continue;
+    }
+    if (sv->post && sv->ibm && sv->side && sv->model == LBM_MODEL_BGK && depth >= 2 && tuning("ibm_depth", 5) >= 2) {
+      const int d = depth < tuning("ibm_depth", 5) ? depth : tuning("ibm_depth", 5);
+      const int rc = solver_ibm_block(sv, d);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        sv->cur ^= 1;
+        sv->steps += d;
+        sv->have_moments = false;  // rho, u hold the ROI rows of the last step only
+        i += d;
+        continue;
+      }
     }
     {
     // with an immersed boundary every step needs this step's rho, u (cylinder_test.cpp:110)

@@ -270,10 +270,12 @@ int sw_launch_walls(double* pn, const double* po, const Geom& g, const Model& m,
   SwSideStream* sd = sw_side_stream();
   hipStream_t fs = st;
   if (sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->st, sd->fork, 0) == hipSuccess) fs = sd->st;
-  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, s0, 32, fs);
-  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, s1, strips - s1, 32, fs);
-  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, ra, s0, s1 - s0, 16, fs);
-  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, rb, row_end, s0, s1 - s0, 16, fs);
+  // frame waves are few and latency-bound: short chunks (8 rows after 2 (D - 1) warm-up rows) keep each
+  // of these launches to one brief round -- on a short row range they would otherwise outlast the interior
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, s0, 8, fs);
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, s1, strips - s1, 8, fs);
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, ra, s0, s1 - s0, 8, fs);
+  sw_launch_part<Model, DV, true>(pn, po, g, m, bc, rb, row_end, s0, s1 - s0, 8, fs);
   sw_launch_part<Model, DV, false>(pn, po, g, m, bc, ra, rb, s0, s1 - s0, 0, st);
   if (fs != st) {
     LBM_CHECK_HIP(hipEventRecord(sd->join, fs));
