@@ -138,7 +138,7 @@ def bench_cylinder(X, Y, n=30):
     lib.solver_set_f_soa_dev(sv.h, _ptr(f))
     del f, u, rho
     dt = timed(lambda k: sv.step(k), n)
-    report("BGK + IBM cylinder (d=300, %d markers)" % m, X, Y, dt, 144, dict(note="rho, u written on the ROI rows only; forcing (one workgroup) overlapped on a side stream"))
+    report("BGK + IBM cylinder (d=300, %d markers)" % m, X, Y, dt, 144, dict(note="5 steps per block: forced band around the ROI on a shrinking trapezoid (single steps), rows farther away through the 5-step window"))
     sv.close(); ib.close()
 
 
@@ -181,3 +181,4 @@ if __name__ == "__main__":
     if "ibm" in which:
         bench_cylinder(16384 // 8, 4096)   # one 8-GPU slab of config 5
         bench_cylinder(4096, 4096)
+        bench_cylinder(16384, 4096)      # config 5 whole on one GPU
