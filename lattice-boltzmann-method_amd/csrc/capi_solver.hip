@@ -221,6 +221,12 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
   int rc = lbm_ibm_roi(sv->ibm, &q0, &q1, &c0, &c1);
   if (rc) return rc;
   const int R = sv->g.R;
+  // the far rows need edges the multi-step window carries (periodic, bounce-back, specular, velocity)
+  auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
+  const lbm_bc& b = sv->bc;
+  if (b.pressure_rows || !carried(b.row_lo) || !carried(b.row_hi) || !carried(b.col_lo) || !carried(b.col_hi) ||
+      sv->bgk.force_mode)
+    return 1;
   if (D < 2 || q0 - 2 * D < 2 || q1 + 2 * D > R - 2 || R < 4 * D + 8 || sv->g.C < 64) return 1;
   if (!sv->band) {
     const size_t bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);

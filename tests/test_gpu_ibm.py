@@ -214,3 +214,30 @@ def test_moving_boundary_extension(lib, oracle):
     assert Fs_ref[0] < 0                                   # F acts on the fluid: the stationary cylinder resists the +r stream
     assert abs(Fs_co[0]) < 0.05 * abs(Fs_ref[0])           # co-moving markers: almost no force
     assert Fs_counter[0] < 1.5 * Fs_ref[0]                 # counter-moving: larger resistance (more negative)
+
+
+@pytest.mark.parametrize("cx_frac", [0.5, 0.12])
+def test_forced_band_blocks_equal_single_steps(lib, oracle, cx_frac):
+    """lbm_solver_step with an immersed boundary advances D steps per block (forced band around the ROI
+    on a shrinking trapezoid + D-step window for the rows farther away; tuning ibm_depth = 5 default, 3)
+    or one step per launch (ibm_depth = 1): same bits after 13 steps (two blocks + singles), and equal
+    to the oracle.  cx_frac = 0.12 puts the ROI too close to the inlet for a block: silent fallback."""
+    X, Y, omega, u_in, radius = 160, 128, 1.0 / 0.55, 0.05, 8.0
+    x, y = circle(X * cx_frac + 0.3, Y / 2.0 - 0.4, radius)
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+    res = {}
+    try:
+        for depth in (1, 5, 3):
+            lib.set_tuning(b"ibm_depth", depth)
+            sv, ib = cylinder_solver(lib, X, Y, omega, u_in, x, y)
+            sv.set_f(f0)
+            sv.step(13, record_moments=False)
+            res[depth] = (sv.get_f(), ib.surface_force())
+            sv.close(); ib.close()
+    finally:
+        lib.set_tuning(b"ibm_depth", -1)
+    fo, uo, rhoo, Fso = oracle.cylinder_steps(x, y, f0, omega, u_in, 13)
+    for depth, (f, Fs) in res.items():
+        assert bits_equal(f, fo), (depth, ulp_diff(f, fo))
+        assert np.allclose(Fs, Fso, rtol=1e-11, atol=1e-16)
