@@ -239,12 +239,10 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
   for (int k = 1; k <= D; ++k) {
     double* out = ((D - k) % 2 == 0) ? dst : sv->band;
     const int lo = q0 - 2 * D + k, hi = q1 + 2 * D - k;
-    rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, q0, q1, sv->rho, sv->u, sv->st);
-    if (rc) return rc;
-    // one stream: beside the forcing workgroup there are only the few rows of the band to run, and a
-    // cross-stream dependency costs more than they take
-    rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, lo, q0, nullptr, nullptr, sv->st);
-    if (!rc) rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, q1, hi, nullptr, nullptr, sv->st);
+    // the whole band in ONE launch (rho, u are written for its rows outside the ROI too: harmless, and
+    // four launches fewer per step), then the forcing on the same stream: beside its one workgroup
+    // there is nothing left to run, and a cross-stream dependency costs more than it could hide
+    rc = lbm_bgk_stream_collide(out, in, &sv->g, &sv->bc, &sv->bgk, lo, hi, sv->rho, sv->u, sv->st);
     if (!rc) rc = lbm_ibm_step(sv->ibm, out, &sv->g, sv->u, sv->rho, sv->bgk.omega, sv->guo_a, sv->guo_b, sv->st);
     if (rc) return rc;
     in = out;
