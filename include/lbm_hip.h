@@ -511,7 +511,8 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * "sw_rows" (rows per wavefront chunk; default: fitted per launch to the resident wave slots, 64 when the launch is many rounds deep), "sw_waves" (waves per workgroup, default 4; 2 for
  * the reassociated BGK model), "sw_xcd" (G > 0: G consecutive strip groups per XCD; measured no effect);
  * "solver_depth" (steps lbm_solver_step fuses per launch on periodic BGK blocks, default 5, 1 =
- * off), "solver_depth_walls" (the same on wall-bounded blocks, default 5), "ibm_depth" (steps lbm_solver_step advances per block on a BGK lattice with an immersed boundary: forced
+ * off), "solver_depth_walls" (the same on wall-bounded blocks, default 5), "bgk_fast_delta" (0 [default]: delta-form BGK parameters always run the reference operation order;
+ * 1: they may use the reassociated model too, 1e-10 instead of bitwise on the cylinder preset), "ibm_depth" (steps lbm_solver_step advances per block on a BGK lattice with an immersed boundary: forced
  * band around the ROI in single steps, rows at least that far away through the multi-step window; default 5,
  * 1 = one step per launch everywhere; same bits), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
  * forcing workgroup is resident; 0: off), "sw_split" (1 [default]: wall-bounded

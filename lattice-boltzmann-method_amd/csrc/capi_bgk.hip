@@ -62,8 +62,11 @@ static int launch_pressure_rows(bool from_post, double* pn, const double* in, co
 // (bit-identical to the oracle); lattices with pressure rows keep it throughout (those rows
 // re-collide their source rows in that order).
 static bool use_fast_bgk(const lbm_bgk_params* prm, const lbm_bc* bc) {
-  return !prm->force_mode && !prm->incompressible && !prm->delta_form && !(bc && bc->pressure_rows) &&
-         tuning("bgk_fast", 1);
+  // delta form f - omega (f - feq) is the same polynomial as (1 - omega) f + omega feq: the reassociated model
+  // may stand in for it, but only on request ("bgk_fast_delta" = 1) -- the cylinder and loop presets are held
+  // bitwise to the oracle by default
+  return !prm->force_mode && !prm->incompressible && (!prm->delta_form || tuning("bgk_fast_delta", 0)) &&
+         !(bc && bc->pressure_rows) && tuning("bgk_fast", 1);
 }
 
 static int check_bgk(const char* fn, const lbm_bgk_params* prm) {

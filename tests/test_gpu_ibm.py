@@ -241,3 +241,26 @@ def test_forced_band_blocks_equal_single_steps(lib, oracle, cx_frac):
     for depth, (f, Fs) in res.items():
         assert bits_equal(f, fo), (depth, ulp_diff(f, fo))
         assert np.allclose(Fs, Fso, rtol=1e-11, atol=1e-16)
+
+
+def test_cylinder_with_reassociated_delta_form(lib, oracle):
+    """Opt-in (tuning bgk_fast_delta = 1): the cylinder preset's delta-form collision through the
+    reassociated model -- not bitwise any more, 1e-10 relative on f after 13 steps (north star: 1e-8)."""
+    X, Y, omega, u_in, radius = 160, 128, 1.0 / 0.55, 0.05, 8.0
+    x, y = circle(X * 0.5 + 0.3, Y / 2.0 - 0.4, radius)
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+    fo, uo, rhoo, Fso = oracle.cylinder_steps(x, y, f0, omega, u_in, 13)
+    try:
+        lib.set_tuning(b"bgk_fast_delta", 1)
+        lib.set_tuning(b"bgk_fast", 1)
+        sv, ib = cylinder_solver(lib, X, Y, omega, u_in, x, y)
+        sv.set_f(f0)
+        sv.step(13, record_moments=False)
+        f, Fs = sv.get_f(), ib.surface_force()
+        sv.close(); ib.close()
+    finally:
+        lib.set_tuning(b"bgk_fast_delta", -1)
+        lib.set_tuning(b"bgk_fast", -1)
+    assert relerr(f, fo) < 1e-10, relerr(f, fo)
+    assert np.allclose(Fs, Fso, rtol=1e-8, atol=1e-14)
