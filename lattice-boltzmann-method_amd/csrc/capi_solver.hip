@@ -228,11 +228,7 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
       sv->bgk.force_mode)
     return 1;
   if (D < 2 || q0 - 2 * D < 2 || q1 + 2 * D > R - 2 || R < 4 * D + 8 || sv->g.C < 64) return 1;
-  if (!sv->band) {
-    const size_t bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
-    LBM_CHECK_HIP(hipMalloc(&sv->band, bytes));
-    LBM_CHECK_HIP(hipMemsetAsync(sv->band, 0, bytes, sv->st));
-  }
+  if (!sv->band) return 1;  // allocated by lbm_solver_attach_ibm (no allocation inside a step call)
   const double* src = sv->lat[sv->cur];
   double* dst = sv->lat[sv->cur ^ 1];
   const double* in = src;
@@ -356,6 +352,11 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
     LBM_CHECK_HIP(hipStreamCreateWithFlags(&sv->side, hipStreamNonBlocking));
     LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_roi, hipEventDisableTiming));
     LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_ibm, hipEventDisableTiming));
+  }
+  if (ib && !sv->band && sv->model == LBM_MODEL_BGK) {  // third lattice of the 5-step blocks (solver_ibm_block)
+    const size_t bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
+    LBM_CHECK_HIP(hipMalloc(&sv->band, bytes));
+    LBM_CHECK_HIP(hipMemsetAsync(sv->band, 0, bytes, sv->st));
   }
   sv->guo_a = guo_a;
   sv->guo_b = guo_b;
