@@ -404,6 +404,12 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
 int lbm_ring_kbc_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
                       const lbm_kbc_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
 
+/* phase timing for diagnosing a scaling run: on = 1 records timed events around the edge rows, the
+ * exchange (pack + send/recv + unpack) and the interior rows of every bgk / kbc launch-step;
+ * lbm_ring_last_timing waits for the last one: out4 = {edge_rows_ms, exchange_ms, interior_ms, span_ms} */
+int lbm_ring_profile(lbm_ring* rg, int on);
+int lbm_ring_last_timing(lbm_ring* rg, double* out4);
+
 /* one overlapped step of a two-phase (colour-gradient) slab: lbm_cg_step_fused on edge and interior
  * rows + ONE exchange of the 3 ghost rows of both colours (slab ghost must be 3; bc NULL = the
  * driver's walls, seams become HALO) */

@@ -125,6 +125,7 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || bc_is_wall(m); };
   LBM_REQUIRE(carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) && !bc.pressure_rows,
               "%s: multi-step launches carry periodic / halo / bounce-back / specular / velocity edges only", fn);
+  LBM_REQUIRE(!bc_mixed_axis(bc), "%s: multi-step launches need both edges of an axis walled or neither", fn);
   const bool walls = bc_needs_edge_pass(bc);
   LBM_REQUIRE(!walls || (lg->ghost == 0 && depth <= 3), "%s: wall-carrying launches are single-block only, 2..3 steps", fn);
   LBM_REQUIRE(lg->ghost == 0 || lg->ghost >= depth, "%s: ghost=%d rows, need 0 or >= %d", fn, lg->ghost, depth);

@@ -86,6 +86,9 @@ struct lbm_ring {
   hipStream_t aux;               // immersed-boundary rows + forcing chain (created on first use)
   hipEvent_t main_done, edge_done, aux_done;
   double *send_next, *send_prev, *recv_prev, *recv_next;
+  // lbm_ring_profile(1): timed events around the three phases of the last launch-step
+  int profile;
+  hipEvent_t t_edge0, t_edge1, t_xchg1, t_main0, t_main1;
 };
 
 using namespace lbm;
@@ -153,6 +156,8 @@ int lbm_ring_destroy(lbm_ring* rg) {
   if (rg->main_done) (void)hipEventDestroy(rg->main_done);
   if (rg->edge_done) (void)hipEventDestroy(rg->edge_done);
   if (rg->aux_done) (void)hipEventDestroy(rg->aux_done);
+  for (hipEvent_t ev : {rg->t_edge0, rg->t_edge1, rg->t_xchg1, rg->t_main0, rg->t_main1})
+    if (ev) (void)hipEventDestroy(ev);
   if (rg->aux) {
     (void)hipStreamSynchronize(rg->aux);
     (void)hipStreamDestroy(rg->aux);
@@ -277,11 +282,21 @@ static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main,
   // edge stream starts after everything previously enqueued on main (src complete)
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+  const bool prof = rg->profile != 0;
+  if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_edge0, rg->edge));
   int rc = rows(0, edge_rows, rg->edge);
   if (!rc) rc = rows(R - edge_rows, R, rg->edge);
-  if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
-  if (!rc) rc = ring_exchange(rg, dst, nullptr, rg->edge, full);
   if (rc) return rc;
+  if (prof) {
+    LBM_CHECK_HIP(hipEventRecord(rg->t_edge1, rg->edge));
+    LBM_CHECK_HIP(hipEventRecord(rg->t_main0, main));
+  }
+  rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
+  if (rc) return rc;
+  if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_main1, main));
+  rc = ring_exchange(rg, dst, nullptr, rg->edge, full);
+  if (rc) return rc;
+  if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_xchg1, rg->edge));
   LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
   LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
   return LBM_OK;
@@ -392,6 +407,38 @@ int lbm_ring_bgk_step_ibm(lbm_ring* rg, double* dst, const double* src, const lb
   if (rc) return rc;
   LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
   if (ib) LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->aux_done, 0));
+  return LBM_OK;
+}
+
+// Phase timing of launch-steps (diagnosis of a scaling run): on = 1 makes lbm_ring_bgk_step /
+// lbm_ring_kbc_step record timed events around the edge rows, the exchange (pack + send/recv +
+// unpack) and the interior rows of every launch-step; lbm_ring_last_timing waits for the last one
+// and returns {edge_rows_ms, exchange_ms, interior_ms, span_ms} (span: first edge row -> the later of
+// exchange end / interior end).  Off (default) records nothing.
+int lbm_ring_profile(lbm_ring* rg, int on) {
+  LBM_REQUIRE(rg, "lbm_ring_profile: NULL ring");
+  if (on && !rg->t_edge0)
+    for (hipEvent_t* ev : {&rg->t_edge0, &rg->t_edge1, &rg->t_xchg1, &rg->t_main0, &rg->t_main1})
+      LBM_CHECK_HIP(hipEventCreate(ev));
+  rg->profile = on ? 1 : 0;
+  return LBM_OK;
+}
+
+int lbm_ring_last_timing(lbm_ring* rg, double* out4) {
+  LBM_REQUIRE(rg && out4, "lbm_ring_last_timing: NULL argument");
+  LBM_REQUIRE(rg->profile && rg->t_edge0, "lbm_ring_last_timing: profiling is off (lbm_ring_profile)");
+  LBM_CHECK_HIP(hipEventSynchronize(rg->t_xchg1));
+  LBM_CHECK_HIP(hipEventSynchronize(rg->t_main1));
+  float edge = 0, xchg = 0, inner = 0, span_x = 0, span_m = 0;
+  LBM_CHECK_HIP(hipEventElapsedTime(&edge, rg->t_edge0, rg->t_edge1));
+  LBM_CHECK_HIP(hipEventElapsedTime(&xchg, rg->t_edge1, rg->t_xchg1));
+  LBM_CHECK_HIP(hipEventElapsedTime(&inner, rg->t_main0, rg->t_main1));
+  LBM_CHECK_HIP(hipEventElapsedTime(&span_x, rg->t_edge0, rg->t_xchg1));
+  LBM_CHECK_HIP(hipEventElapsedTime(&span_m, rg->t_edge0, rg->t_main1));
+  out4[0] = edge;
+  out4[1] = xchg;
+  out4[2] = inner;
+  out4[3] = span_x > span_m ? span_x : span_m;
   return LBM_OK;
 }
 

@@ -225,7 +225,7 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
   auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
   const lbm_bc& b = sv->bc;
   if (b.pressure_rows || !carried(b.row_lo) || !carried(b.row_hi) || !carried(b.col_lo) || !carried(b.col_hi) ||
-      sv->bgk.force_mode)
+      sv->bgk.force_mode || bc_mixed_axis(make_bc(&b)))
     return 1;
   if (D < 2 || q0 - 2 * D < 2 || q1 + 2 * D > R - 2 || R < 4 * D + 8 || sv->g.C < 64) return 1;
   if (!sv->band) return 1;  // allocated by lbm_solver_attach_ibm (no allocation inside a step call)
@@ -255,7 +255,7 @@ static bool solver_can_fuse_steps(const lbm_solver* sv) {
   const bool bgk = sv->model == LBM_MODEL_BGK;
   auto plain = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
   const bool model_ok = bgk || (sv->model == LBM_MODEL_KBC && tuning("kbc_fast", 1));
-  return model_ok && !sv->ibm && !b.pressure_rows && plain(b.row_lo) && plain(b.row_hi) &&
+  return model_ok && !sv->ibm && !b.pressure_rows && !bc_mixed_axis(make_bc(&b)) && plain(b.row_lo) && plain(b.row_hi) &&
          plain(b.col_lo) && plain(b.col_hi) && sv->g.C >= 64;
 }
 

@@ -183,6 +183,16 @@ __host__ __device__ inline bool bc_is_wall(int m) {
   return m == LBM_EDGE_BOUNCE_BACK || m == LBM_EDGE_SPECULAR || m == LBM_EDGE_ABB_VELOCITY;
 }
 
+// An axis with a wall on one side and PERIODIC on the other: the single-step gather handles it, the
+// multi-step window does not (its column clamp / row wrap are per axis, not per side) -- launchers
+// reject it and the solver falls back to single steps.  Wall + HALO (a chain-end slab) is fine.
+inline bool bc_mixed_axis(const Bc& b) {
+  auto mixed = [](int lo, int hi) {
+    return (bc_is_wall(lo) && hi == LBM_EDGE_PERIODIC) || (bc_is_wall(hi) && lo == LBM_EDGE_PERIODIC);
+  };
+  return mixed(b.row_lo, b.row_hi) || mixed(b.col_lo, b.col_hi);
+}
+
 __device__ __forceinline__ bool is_edge_node(const Geom& g, int r, int c) {
   return r == 0 || r == g.R - 1 || c == 0 || c == g.C - 1;
 }

@@ -9,7 +9,8 @@
 
 namespace lbm {
 
-inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc) {
+// reads_neighbours: the caller streams (pulls from neighbouring rows); collide-only entry points pass false
+inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc, bool reads_neighbours = true) {
   LBM_REQUIRE(g, "%s: NULL geometry", fn);
   LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
   LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 8, "%s: ghost=%d must be 0..8", fn, g->ghost);
@@ -35,6 +36,11 @@ inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc)
       LBM_REQUIRE(bc->row_lo != LBM_EDGE_HALO && bc->row_hi != LBM_EDGE_HALO,
                   "%s: HALO rows need ghost rows (ghost >= 1)", fn);
   }
+  // with ghost rows nothing wraps: a PERIODIC row edge (NULL bc = all periodic) would silently read
+  // ghost rows nobody fills
+  if (reads_neighbours && g->ghost > 0)
+    LBM_REQUIRE(bc && bc->row_lo != LBM_EDGE_PERIODIC && bc->row_hi != LBM_EDGE_PERIODIC,
+                "%s: a lattice with ghost rows needs HALO or wall row edges (PERIODIC given)", fn);
   return LBM_OK;
 }
 
@@ -298,6 +304,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || bc_is_wall(m); };
   LBM_REQUIRE(carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) && !bc.pressure_rows,
               "%s: multi-step launches carry periodic / halo / bounce-back / specular / velocity edges only", fn);
+  LBM_REQUIRE(!bc_mixed_axis(bc), "%s: multi-step launches need both edges of an axis walled or neither (wall + PERIODIC on one axis: use single steps)", fn);
   const bool walls = bc_needs_edge_pass(bc);
   // (over slabs the ghost rows must then be COMPLETE: exchange with LBM_HALO_FULL(depth))
   LBM_REQUIRE(depth >= 2 && depth <= (walls ? 5 : 6), "%s: %d steps per launch (supported: 2..%d)", fn, depth, walls ? 5 : 6);
@@ -357,7 +364,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
 template <class Model>
 int launch_collide_only(const char* fn, double* p, const double* f, const lbm_geom* lg,
                         const lbm_bc* lbc, const Model& m, double* rho, double* u, hipStream_t st) {
-  int rc = validate_geom_bc(fn, lg, lbc);
+  int rc = validate_geom_bc(fn, lg, lbc, false);
   if (rc) return rc;
   LBM_REQUIRE(p && f, "%s: NULL lattice", fn);
   LBM_REQUIRE((rho == nullptr) == (u == nullptr), "%s: rho and u must both be given or both NULL", fn);

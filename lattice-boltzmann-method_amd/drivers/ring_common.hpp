@@ -1,6 +1,7 @@
 // shared by the slab-ring drivers: status check, the file rendezvous that distributes the RCCL
 // unique id (no MPI in this image), and the fork-one-rank-per-GPU launcher.
 #pragma once
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -42,7 +43,10 @@ inline void wait_file(const std::string& path, void* buf, size_t n, double timeo
 }
 
 
-// fork BEFORE anything touches the GPU; every child is an ordinary one-GPU process
+// fork BEFORE anything touches the GPU; every child is an ordinary one-GPU process.  Children are
+// reaped in exit order: the first one that fails takes its peers with it (SIGTERM, then SIGKILL
+// after a grace period) -- a rank blocked in ncclCommInitRank / send / recv on a dead peer would
+// otherwise hold its GPU until an outer timeout.
 template <class F>
 int spawn_ranks(int n, F&& run) {
   std::vector<pid_t> kids;
@@ -58,13 +62,38 @@ int spawn_ranks(int n, F&& run) {
       std::fflush(nullptr);
       _exit(rc);
     }
+    if (pid < 0) {
+      std::perror("fork");
+      for (pid_t k : kids) kill(k, SIGKILL);
+      for (pid_t k : kids) waitpid(k, nullptr, 0);
+      return 1;
+    }
     kids.push_back(pid);
   }
   int worst = 0;
-  for (pid_t k : kids) {
+  size_t left = kids.size();
+  bool killing = false;
+  auto t_kill = std::chrono::steady_clock::now();
+  while (left > 0) {
     int st = 0;
-    waitpid(k, &st, 0);
-    if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) worst = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+    pid_t k = waitpid(-1, &st, killing ? WNOHANG : 0);
+    if (k > 0) {
+      --left;
+      const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
+      if (rc != 0 && worst == 0) worst = rc;
+      if (rc != 0 && !killing) {  // first failure: stop the survivors
+        killing = true;
+        t_kill = std::chrono::steady_clock::now();
+        for (pid_t o : kids)
+          if (o != k) kill(o, SIGTERM);
+      }
+    } else if (k == 0) {  // survivors still running after SIGTERM
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_kill).count() > 5.0)
+        for (pid_t o : kids) kill(o, SIGKILL);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    } else {
+      break;  // ECHILD: nothing left to wait for
+    }
   }
   return worst;
 }

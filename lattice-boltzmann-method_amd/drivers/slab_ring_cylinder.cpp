@@ -212,6 +212,7 @@ int main(int argc, char** argv) {
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
   try {
     if (spawn > 0) {
+      cleanup_ring_files(a.id_file, spawn);  // a stale id file of a killed run must not be picked up
       const int rc = spawn_ranks(spawn, [&](int r) { return run_rank(a, r, spawn, r); });
       cleanup_ring_files(a.id_file, spawn);
       return rc;

@@ -91,8 +91,12 @@ def test_newer_entry_points_validate_before_touching_the_gpu():
     with pytest.raises(pylbm.LbmError, match="supported: 2..4"):
         lib.kbc_stream_collide_xn(None, None, ct.byref(g), None, ct.byref(prm), 7, 0, 16, None)
     cg = pylbm.cg_params()
+    with pytest.raises(pylbm.LbmError, match="needs HALO or wall row edges"):   # NULL bc = periodic on a ghost-row geometry
+        lib.cg_step_fused(None, None, None, None, ct.byref(pylbm.Geom(16, 16, 3)), None, ct.byref(cg), 0, 16,
+                          None, None, None, None, None, None)
     with pytest.raises(pylbm.LbmError, match="0 or 3 ghost rows"):
-        lib.cg_step_fused(None, None, None, None, ct.byref(pylbm.Geom(16, 16, 2)), None, ct.byref(cg), 0, 16,
+        lib.cg_step_fused(None, None, None, None, ct.byref(pylbm.Geom(16, 16, 2)),
+                          ct.byref(pylbm.Bc(row_lo=pylbm.EDGE_HALO, row_hi=pylbm.EDGE_HALO)), ct.byref(cg), 0, 16,
                           None, None, None, None, None, None)
     with pytest.raises(pylbm.LbmError, match="NULL argument"):
         lib.pressure_row(None, ct.byref(g), 0, None, None, None, ct.byref(g), 1, ct.c_double(1.0), 0, None)

@@ -782,3 +782,57 @@ def test_wall_split_launches_replay_from_a_captured_graph(lib, oracle):
         if graph:
             lib.graph_destroy(graph)
         lib.stream_destroy(st)
+
+
+@pytest.mark.parametrize("axis", ["cols", "rows"])
+def test_mixed_wall_and_periodic_axis_falls_back_to_single_steps(lib, oracle, axis):
+    """A wall on one side of an axis and PERIODIC on the other: the single-step gather
+    handles it, the multi-step window does not (column clamp / row wrap are per axis) -- the
+    launcher must refuse it and lbm_solver_step must fall back, so that n fused driver iterations
+    equal n single-step launches bit for bit."""
+    R, C = 96, 150
+    bc = pylbm.Bc.periodic()
+    if axis == "cols":
+        bc.col_lo = pylbm.EDGE_BOUNCE_BACK
+    else:
+        bc.row_hi = pylbm.EDGE_BOUNCE_BACK
+    prm = pylbm.BgkParams(1.3, 0)
+    f0 = random_state(oracle, R, C, seed=5)
+    g = pylbm.Geom(R, C, 0)
+    p0 = upload_soa(lib, f0)
+    a, b = torch.empty_like(p0), torch.empty_like(p0)
+    with pytest.raises(pylbm.LbmError, match="both edges of an axis"):
+        lib.bgk_stream_collide_xn(_ptr(b), _ptr(p0), ct.byref(g), ct.byref(bc), ct.byref(prm), 3, 0, R, None)
+    n = 7
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, prm, bc=bc)
+    sv.set_f(f0)
+    sv.step(n)
+    got = sv.get_f()
+    sv.close()
+    # the same through explicit launches: collide-only, n - 1 single steps, stream at the end
+    lib.bgk_collide(_ptr(a), _ptr(p0), ct.byref(g), ct.byref(bc), ct.byref(prm), None, None, None)
+    for _ in range(n - 1):
+        lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(g), ct.byref(bc), ct.byref(prm), 0, R, None, None, None)
+        a, b = b, a
+    lib.stream(_ptr(b), _ptr(a), ct.byref(g), ct.byref(bc), None)
+    torch.cuda.synchronize()
+    assert _bits_equal(got, download_aos(lib, b))
+
+
+def test_ghost_rows_reject_periodic_row_edges(lib):
+    """with ghost rows nothing wraps: a PERIODIC (or NULL = periodic) bc on a ghost-row geometry would
+    read ghost rows nobody fills -- rejected with an error, not silently computed"""
+    R, C = 64, 64
+    g = pylbm.Geom(R, C, 1)
+    a = torch.zeros((9, R + 2, C), dtype=torch.float64, device=dev())
+    b = torch.zeros_like(a)
+    prm = pylbm.BgkParams(1.0, 0)
+    with pytest.raises(pylbm.LbmError, match="ghost rows"):
+        lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(g), None, ct.byref(prm), 0, R, None, None, None)
+    bc = pylbm.Bc.periodic()
+    bc.row_lo = pylbm.EDGE_HALO   # row_hi stays PERIODIC
+    with pytest.raises(pylbm.LbmError, match="ghost rows"):
+        lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(g), ct.byref(bc), ct.byref(prm), 0, R, None, None, None)
+    bc.row_hi = pylbm.EDGE_HALO
+    lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(g), ct.byref(bc), ct.byref(prm), 0, R, None, None, None)
+    torch.cuda.synchronize()
