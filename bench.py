@@ -172,7 +172,7 @@ class Box:
 def timed_batches(box, steps, repeats, world, dev):
     """`repeats` batches of exactly `steps` steps, each bracketed by barrier + synchronize; returns
     per-repeat (wall seconds, device ms between HIP events on the launch stream), MAX over ranks."""
-    wall, devms = [], []
+    wall, devms, enq = [], [], []
     for _ in range(repeats):
         torch.cuda.synchronize()
         if world > 1:
@@ -183,16 +183,17 @@ def timed_batches(box, steps, repeats, world, dev):
         ev0.record()
         box.advance(steps)
         ev1.record()
+        enq.append(time.perf_counter() - t0)    # host time to ENQUEUE the batch (GPU-bound runs: well below wall)
         torch.cuda.synchronize()
         wall.append(time.perf_counter() - t0)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         devms.append(ev0.elapsed_time(ev1))
-    t = torch.tensor([wall, devms], dtype=torch.float64, device=dev)
+    t = torch.tensor([wall, devms, enq], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t[0].tolist(), t[1].tolist()
+    return t[0].tolist(), t[1].tolist(), t[2].tolist()
 
 
 def main():
@@ -265,9 +266,9 @@ def main():
     # -- timed region --------------------------------------------------------------------------
     repeats = a.repeats
     if repeats <= 0:
-        w1, _ = timed_batches(box, a.steps, 1, world, dev)           # pilot batch (also warm-up)
+        w1, _, _ = timed_batches(box, a.steps, 1, world, dev)        # pilot batch (also warm-up)
         repeats = max(5, min(25, int(2.5 / max(w1[0], 1e-6))))
-    wall, devms = timed_batches(box, a.steps, repeats, world, dev)
+    wall, devms, enq = timed_batches(box, a.steps, repeats, world, dev)
     order = sorted(range(repeats), key=lambda i: wall[i])
     mid = order[repeats // 2]
     dt, dev_ms = wall[mid], devms[mid]
@@ -305,7 +306,7 @@ def main():
     if world == 1 and D >= 2 and fast:
         lib.set_tuning(b"bgk_fast", 0)
         box.advance(4 * D)
-        w2, _ = timed_batches(box, a.steps, 5, world, dev)
+        w2, _, _ = timed_batches(box, a.steps, 5, world, dev)
         ref_order = {"value": round(R * C * a.steps / statistics.median(w2) / 1e6, 1), "unit": "MLUPS",
                      "steps": a.steps, "repeats": 5, "kernel": f"k_stream_collide_sw<BgkModelT<0,0>,{D},4,nt>",
                      "note": "same schedule, collision in the reference's operation order (bitwise equal to the CPU oracle)"}
@@ -374,6 +375,7 @@ def main():
                                    "steps, each bracketed by barrier + synchronize, MAX over ranks; value = median batch",
                        "warm_steps_run": warm_steps,
                        "batch_ms": {"min": round(min(wall) * 1e3, 4), "median": round(dt * 1e3, 4), "max": round(max(wall) * 1e3, 4)},
+                       "host_enqueue_ms": round(statistics.median(enq) * 1e3, 4),
                        "timed_region_s": round(sum(wall), 4)},
             "roofline": roof,
             "check": {"total_mass": float(mass), "expected_mass": float(R * C * world)},

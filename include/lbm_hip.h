@@ -189,6 +189,12 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
 int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
                               const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
                               int row_begin, int row_end, lbm_stream_t s);
+/* the same on TWO row ranges of equal height in one launch: [row_begin, row_end) and [row_begin2,
+ * row_begin2 + (row_end - row_begin)), row_begin2 >= row_end -- the edge rows at both ends of a slab
+ * ahead of the halo exchange (block binding, test/decompose_domain.cpp:181-187) */
+int lbm_bgk_stream_collide_xn2(double* p_new, const double* p_old, const lbm_geom* g,
+                               const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
+                               int row_begin, int row_end, int row_begin2, lbm_stream_t s);
 /* f = stream(p) incl. boundary fix-ups == solver::advect + the driver's post-advect BCs. */
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s);
 
@@ -368,6 +374,10 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments);
 /* host AoS rho[R][C], u[R][C][2] recorded by the last step(.., 1) */
 int lbm_solver_get_moments_aos(lbm_solver* sv, double* rho_host, double* u_host);
 int lbm_solver_sync(lbm_solver* sv);
+/* how many multi-step blocks lbm_solver_step has launched so far (periodic / wall-bounded windows,
+ * immersed-boundary blocks, pressure-row blocks): lets a caller or a test see that steps were fused
+ * rather than silently run one per launch; -1 for NULL */
+long long lbm_solver_block_launches(const lbm_solver* sv);
 /* attach an immersed boundary to a BGK solver: every step then runs lbm_ibm_force on the
  * step's moments and adds the Guo source (a, b) on the ROI, as cylinder_test.cpp:110-127.
  * The solver does not take ownership. */
@@ -520,7 +530,8 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * off), "solver_depth_walls" (the same on wall-bounded blocks, default 5), "bgk_fast_delta" (0 [default]: delta-form BGK parameters always run the reference operation order;
  * 1: they may use the reassociated model too, 1e-10 instead of bitwise on the cylinder preset), "ibm_depth" (steps lbm_solver_step advances per block on a BGK lattice with an immersed boundary: forced
  * band around the ROI in single steps, rows at least that far away through the multi-step window; default 5,
- * 1 = one step per launch everywhere; same bits), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
+ * 1 = one step per launch everywhere; same bits), "pressure_depth" (steps per block on lattices with pressure-periodic rows: the 2 D rows on either side of the virtual rows in single steps on a small periodic
+ * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
  * forcing workgroup is resident; 0: off), "sw_split" (1 [default]: wall-bounded
  * multi-step launches run their wall-free interior through the plain instantiation and only the frame of
  * outermost strips / rows next to a wall row through the wall-carrying one, on a helper stream; 0: one

@@ -132,26 +132,42 @@ int lbm_bgk_stream_collide_x2(double* p_new, const double* p_old, const lbm_geom
                                   row_end, as_stream(s));
 }
 
-int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
-                              const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
-                              int row_begin, int row_end, lbm_stream_t s) {
-  int rc = check_bgk("lbm_bgk_stream_collide_xn", prm);
+static int bgk_xn(const char* fn, double* p_new, const double* p_old, const lbm_geom* g, const lbm_bc* bc,
+                  const lbm_bgk_params* prm, int n_steps, int row_begin, int row_end, int second_begin,
+                  lbm_stream_t s, bool allow_fast = true) {
+  int rc = check_bgk(fn, prm);
   if (rc) return rc;
-  const char* fn = "lbm_bgk_stream_collide_xn";
   if (!prm->force_mode) {  // compile-time model: no mode branches inside the unrolled window
     const int key = (prm->incompressible ? 2 : 0) | (prm->delta_form ? 1 : 0);
-    if (use_fast_bgk(prm, bc))  // leaner collision: best at one 2-wave block per SIMD pair (146.6 k vs 137 k MLUPS)
-      return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkFastModel(prm->omega), n_steps, row_begin, row_end, as_stream(s), 2);
+    if (allow_fast && use_fast_bgk(prm, bc))  // leaner collision: best at one 2-wave block per SIMD pair (146.6 k vs 137 k MLUPS)
+      return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkFastModel(prm->omega), n_steps, row_begin, row_end, as_stream(s), 2, second_begin);
     switch (key) {
-      case 0: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
-      case 1: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
-      case 2: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<1, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
-      default: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<1, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s));
+      case 0: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s), 4, second_begin);
+      case 1: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<0, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s), 4, second_begin);
+      case 2: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<1, 0>{prm->omega}, n_steps, row_begin, row_end, as_stream(s), 4, second_begin);
+      default: return launch_stream_collide_sw(fn, p_new, p_old, g, bc, BgkModelT<1, 1>{prm->omega}, n_steps, row_begin, row_end, as_stream(s), 4, second_begin);
     }
   }
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   // runtime-mode model (body force): uncapped 2-wave blocks (the 4-wave variants spill 280-410 VGPRs)
-  return launch_stream_collide_sw(fn, p_new, p_old, g, bc, m, n_steps, row_begin, row_end, as_stream(s), 2);
+  return launch_stream_collide_sw(fn, p_new, p_old, g, bc, m, n_steps, row_begin, row_end, as_stream(s), 2, second_begin);
+}
+
+int lbm_bgk_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom* g,
+                              const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
+                              int row_begin, int row_end, lbm_stream_t s) {
+  return bgk_xn("lbm_bgk_stream_collide_xn", p_new, p_old, g, bc, prm, n_steps, row_begin, row_end, -1, s);
+}
+
+// the same on TWO row ranges of equal height in ONE launch: [row_begin, row_end) and
+// [row_begin2, row_begin2 + (row_end - row_begin)) -- the edge rows at both ends of a slab, which as two
+// launches on one stream would run one after the other (the second queued behind a grid-filling
+// interior launch); wall-bounded lattices fall back to two launches
+int lbm_bgk_stream_collide_xn2(double* p_new, const double* p_old, const lbm_geom* g,
+                               const lbm_bc* bc, const lbm_bgk_params* prm, int n_steps,
+                               int row_begin, int row_end, int row_begin2, lbm_stream_t s) {
+  LBM_REQUIRE(row_begin2 >= 0, "lbm_bgk_stream_collide_xn2: row_begin2=%d", row_begin2);
+  return bgk_xn("lbm_bgk_stream_collide_xn2", p_new, p_old, g, bc, prm, n_steps, row_begin, row_end, row_begin2, s);
 }
 
 int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, lbm_stream_t s) {
@@ -167,3 +183,12 @@ int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, 
 }
 
 }  // extern "C"
+
+// internal (internal.hpp): the far rows of a lattice with pressure rows -- such lattices run the
+// reference operation order on every path (use_fast_bgk), and so must their window launches although
+// the bc they are given has the pressure rows taken out
+int lbm::bgk_stream_collide_xn_ref(double* p_new, const double* p_old, const lbm_geom* g, const lbm_bc* bc,
+                                   const lbm_bgk_params* prm, int n_steps, int row_begin, int row_end, hipStream_t st) {
+  return bgk_xn("bgk_stream_collide_xn_ref", p_new, p_old, g, bc, prm, n_steps, row_begin, row_end, -1, (lbm_stream_t)st, false);
+}
+

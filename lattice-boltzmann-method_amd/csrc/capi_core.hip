@@ -1,5 +1,6 @@
 // C ABI, part 1: status, device memory/stream/event helpers, layout converters and the
 // seven unfused solver:: operators (parity surface, not the hot path).
+#include <cstdint>
 #include <cstring>
 #include <cstdlib>
 #include <map>
@@ -138,16 +139,34 @@ struct HaloTable {
   short q[80];       // population of row i
   short row[80];     // lattice row (owned-row index space; ghost rows negative / >= R) of row i
 };
+// VEC = 2: 16 bytes per lane (C even, planes and buffers 16-byte aligned).  The launch is capped at a
+// few hundred workgroups ("halo_grid"): these copies run beside a grid-filling interior launch, where
+// every extra workgroup waits for a slot -- few fat workgroups finish sooner than many thin ones.
+template <int VEC>
 __global__ __launch_bounds__(256) void k_halo_copy(double* __restrict__ dst,
                                                    const double* __restrict__ src, Geom g,
                                                    HaloTable t, int to_buffer) {
-  const long n = (long)t.n * g.C;
+  const int cv = g.C / VEC;
+  const long n = (long)t.n * cv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const int k = (int)(i / g.C), c = (int)(i % g.C);
-    const long o = t.q[k] * g.plane + g.at(t.row[k], c);
-    if (to_buffer) dst[i] = src[o];
-    else dst[o] = src[i];
+    const int k = (int)(i / cv), c = (int)(i % cv) * VEC;
+    const long o = t.q[k] * g.plane + g.at(t.row[k], c), b = (long)k * g.C + c;
+    if (VEC == 2) {
+      if (to_buffer) *reinterpret_cast<dbl2*>(dst + b) = *reinterpret_cast<const dbl2*>(src + o);
+      else *reinterpret_cast<dbl2*>(dst + o) = *reinterpret_cast<const dbl2*>(src + b);
+    } else {
+      if (to_buffer) dst[b] = src[o];
+      else dst[o] = src[b];
+    }
   }
+}
+static void launch_halo_copy(double* dst, const double* src, const Geom& gg, const HaloTable& t, int to_buffer,
+                             const double* lattice, const double* buf, hipStream_t st) {
+  const bool v2 = gg.C % 2 == 0 && gg.plane % 2 == 0 && ((gg.ghost * (long)gg.C) % 2 == 0) &&
+                  ((uintptr_t)lattice % 16 == 0) && ((uintptr_t)buf % 16 == 0);
+  const int cap = tuning("halo_grid", 256);
+  if (v2) LBM_KLAUNCH(k_halo_copy<2>, dim3(capped_grid(((long)t.n * (gg.C / 2) + 255) / 256, cap)), dim3(256), 0, st, dst, src, gg, t, to_buffer);
+  else LBM_KLAUNCH(k_halo_copy<1>, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, cap)), dim3(256), 0, st, dst, src, gg, t, to_buffer);
 }
 
 // rows of the depth-D halo in message order.  side 1: towards the NEXT slab (c_x = +1 leave);
@@ -214,8 +233,7 @@ int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int dep
   HaloTable t;
   LBM_REQUIRE(halo_table(t, depth, side, true, g->R) > 0, "lbm_halo_pack: depth too large");
   const Geom gg = make_geom(*g);
-  LBM_KLAUNCH(k_halo_copy, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, 1024)), dim3(256), 0, as_stream(s),
-              buf, lattice, gg, t, 1);
+  launch_halo_copy(buf, lattice, gg, t, 1, lattice, buf, as_stream(s));
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
@@ -230,8 +248,7 @@ int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int d
   HaloTable t;
   LBM_REQUIRE(halo_table(t, depth, side, false, g->R) > 0, "lbm_halo_unpack: depth too large");
   const Geom gg = make_geom(*g);
-  LBM_KLAUNCH(k_halo_copy, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, 1024)), dim3(256), 0, as_stream(s),
-              lattice, buf, gg, t, 0);
+  launch_halo_copy(lattice, buf, gg, t, 0, lattice, buf, as_stream(s));
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }

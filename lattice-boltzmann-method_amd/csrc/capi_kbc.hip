@@ -165,6 +165,38 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   return LBM_OK;
 }
 
+}  // namespace lbm
+// Two steps per launch in the reference operation order (KbcModel): the far rows of a lattice with
+// pressure-periodic rows (capi_solver.hip solver_pressure_block).  ~940 f64 operations per collision and
+// a register ring: one wave per SIMD with scratch spills -- it exists for bit-parity with the single-step
+// path, not for speed.
+int lbm::kbc_stream_collide_x2_ref(double* pn, const double* po, const lbm_geom* lg, const lbm_bc* lbc,
+                                   const lbm_kbc_params* prm, int row_begin, int row_end, hipStream_t st) {
+  const char* fn = "kbc_stream_collide_x2_ref";
+  int rc = validate_geom_bc(fn, lg, lbc);
+  if (rc) return rc;
+  LBM_REQUIRE(pn && po && pn != po && prm, "%s: bad argument", fn);
+  LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R, "%s: row range", fn);
+  const Bc bc = make_bc(lbc);
+  auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
+  LBM_REQUIRE(lg->ghost == 0 && carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) &&
+                  !bc.pressure_rows && !bc_mixed_axis(bc) && lg->R >= 16 && lg->C >= 64,
+              "%s: single block with periodic / wall edges only", fn);
+  if (row_begin == row_end) return LBM_OK;
+  const Geom g = make_geom(*lg);
+  const KbcModel m{prm->s2};
+  if (bc_needs_edge_pass(bc)) {
+    rc = sw_launch_walls<KbcModel, 2>(pn, po, g, m, bc, row_begin, row_end, st);
+    if (rc) return rc;
+  } else {
+    const int W = sw_strip_width(2, sw_full_strips<KbcModel>::value), strips = (g.C + W - 1) / W;
+    sw_launch_part<KbcModel, 2, false>(pn, po, g, m, bc, row_begin, row_end, 0, strips, 0, st);
+  }
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+namespace lbm {
+
 static int check_kbc(const char* fn, const lbm_kbc_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->s2 > 0.0 && prm->s2 <= 2.0, "%s: s2=%g outside (0, 2]", fn, prm->s2);

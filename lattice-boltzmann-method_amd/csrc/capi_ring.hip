@@ -276,16 +276,15 @@ int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* s
 // concurrently), halo exchange of dst behind the edge rows.  `rows(r0, r1, stream)` launches the
 // model's kernel on a row range.  On return `main` has been made to wait for everything: the next
 // call may follow immediately.
-template <class Rows>
-static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows, bool full = false) {
+template <class Rows, class Edges>
+static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows, Edges&& edges, bool full = false) {
   const int R = rg->g.R;
   // edge stream starts after everything previously enqueued on main (src complete)
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
   const bool prof = rg->profile != 0;
   if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_edge0, rg->edge));
-  int rc = rows(0, edge_rows, rg->edge);
-  if (!rc) rc = rows(R - edge_rows, R, rg->edge);
+  int rc = edges(rg->edge);  // rows [0, edge_rows) and [R - edge_rows, R)
   if (rc) return rc;
   if (prof) {
     LBM_CHECK_HIP(hipEventRecord(rg->t_edge1, rg->edge));
@@ -318,10 +317,16 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
   // walls + several steps per launch: the NEXT launch reads complete ghost rows
   const bool full = n_steps > 1 && (bc_is_wall(b.row_lo) || bc_is_wall(b.row_hi) || bc_is_wall(b.col_lo) || bc_is_wall(b.col_hi));
-  return ring_step(rg, dst, edge_rows, as_stream(main_s), [&](int r0, int r1, hipStream_t st) -> int {
+  auto rows = [&](int r0, int r1, hipStream_t st) -> int {
     if (n_steps == 1) return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
     return lbm_bgk_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
-  }, full);
+  };
+  auto edges = [&](hipStream_t st) -> int {  // both ends in ONE dispatch where the window kernel runs them
+    if (n_steps > 1 && edge_rows <= 192) return lbm_bgk_stream_collide_xn2(dst, src, &rg->g, &b, prm, n_steps, 0, edge_rows, R - edge_rows, st);
+    int rc = rows(0, edge_rows, st);
+    return rc ? rc : rows(R - edge_rows, R, st);
+  };
+  return ring_step(rg, dst, edge_rows, as_stream(main_s), rows, edges, full);
 }
 
 // KBC: the same schedule (n_steps 1, or 2..4 through the sliding window with the reassociated
@@ -336,10 +341,15 @@ int lbm_ring_kbc_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
   if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
   if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
-  return ring_step(rg, dst, edge_rows, as_stream(main_s), [&](int r0, int r1, hipStream_t st) -> int {
+  auto rows = [&](int r0, int r1, hipStream_t st) -> int {
     if (n_steps == 1) return lbm_kbc_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
     return lbm_kbc_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
-  });
+  };
+  auto edges = [&](hipStream_t st) -> int {
+    int rc = rows(0, edge_rows, st);
+    return rc ? rc : rows(R - edge_rows, R, st);
+  };
+  return ring_step(rg, dst, edge_rows, as_stream(main_s), rows, edges);
 }
 
 // One overlapped single-step launch of a BGK slab that may own an immersed boundary (config 5:

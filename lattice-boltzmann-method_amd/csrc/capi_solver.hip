@@ -25,13 +25,21 @@ struct lbm_solver {
   bool post;        // state is post-collision (P-form); false: pre-collision f_adve
   bool have_moments;
   long steps;
+  long blocks = 0;  // multi-step blocks launched so far (lbm_solver_block_launches)
   lbm_ibm* ibm;  // optional immersed boundary (not owned)
   double guo_a, guo_b;
   bool given_moments = false;  // first iteration collides on sv->rho / sv->u as set by the caller
   hipStream_t side = nullptr;  // forcing chain of the immersed boundary, beside the lattice update
   hipEvent_t ev_roi = nullptr, ev_ibm = nullptr;
   double* band = nullptr;      // third lattice: odd / even steps of the forced band (solver_ibm_block)
+  // pressure-periodic rows at multi-step speed (solver_pressure_block): two small lattices of 4 D rows
+  // holding the rows on both sides of the virtual rows, advanced in single steps on a helper stream
+  double* seam[2] = {nullptr, nullptr};
+  long long seam_plane = 0;
+  hipStream_t seam_st = nullptr;
+  hipEvent_t ev_seam_fork = nullptr, ev_seam_join = nullptr;
 };
+static constexpr int kSeamMaxDepth = 5;
 
 using namespace lbm;
 
@@ -112,6 +120,17 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
   if (e == hipSuccess) e = hipMalloc(&sv->stage, n * 9 * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&sv->rho, n * sizeof(double));
   if (e == hipSuccess) e = hipMalloc(&sv->u, n * 2 * sizeof(double));
+  if (e == hipSuccess && sv->bc.pressure_rows && g->C >= 64 && g->R >= 6 * 2 + 8) {  // solver_pressure_block
+    const int rows = 4 * kSeamMaxDepth;
+    sv->seam_plane = (long long)rows * g->C + 1088;  // off the power-of-two stride, 64-byte aligned
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+      e = hipMalloc(&sv->seam[k], (size_t)sv->seam_plane * 9 * sizeof(double));
+      if (e == hipSuccess) e = hipMemsetAsync(sv->seam[k], 0, (size_t)sv->seam_plane * 9 * sizeof(double), sv->st);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sv->seam_st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sv->ev_seam_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sv->ev_seam_join, hipEventDisableTiming);
+  }
   if (e != hipSuccess) {
     set_error("lbm_solver_create: hipMalloc failed: %s", hipGetErrorString(e));
     lbm_solver_destroy(sv);
@@ -123,7 +142,13 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
 
 int lbm_solver_destroy(lbm_solver* sv) {
   if (!sv) return LBM_OK;
-  for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u, sv->band})
+  if (sv->seam_st) {
+    (void)hipStreamSynchronize(sv->seam_st);
+    (void)hipStreamDestroy(sv->seam_st);
+  }
+  if (sv->ev_seam_fork) (void)hipEventDestroy(sv->ev_seam_fork);
+  if (sv->ev_seam_join) (void)hipEventDestroy(sv->ev_seam_join);
+  for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u, sv->band, sv->seam[0], sv->seam[1]})
     if (p) (void)hipFree(p);
   if (sv->side) {
     (void)hipStreamSynchronize(sv->side);
@@ -248,6 +273,60 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
   return rc;
 }
 
+// D steps of a block with PRESSURE-PERIODIC rows (horizontal_poiseuille_test.cpp:25-45, ulbm_poiseuille.cpp:
+// 36-58).  The virtual rows 0 / R-1 are rewritten every step from the collision of rows R-2 / 1, so no
+// multi-step window can carry them (row R-2 of a level would have to be known before row 1 of the level
+// below).  But a forced value of row 0 at level l reaches row j only at level l + j: rows [D, R - D) see
+// plain arithmetic for D steps and take the multi-step window from the time-t lattice, while the 2 D rows
+// on either side of the seam are copied into a small periodic lattice of 4 D rows (rows [0, 2D) first,
+// rows [R - 2D, R) behind them: its own wrap IS the seam, its virtual rows are ITS rows 0 / 4D - 1) and
+// advance D ordinary single steps there -- the artificial seam in its middle spoils one more row per
+// side and step, leaving rows [0, D) and [3D, 4D) valid, which are copied back.  That chain (3 small
+// launches per step) runs on a helper stream beside the window launch.  Same kernels per node as D
+// single steps: same bits.  Returns 1 if the block does not qualify (caller falls back to single steps).
+static int solver_pressure_block(lbm_solver* sv, int D) {
+  const lbm_bc& b = sv->bc;
+  const int R = sv->g.R, C = sv->g.C;
+  auto col_ok = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
+  if (!sv->seam[0] || !sv->seam_st || D < 2 || D > kSeamMaxDepth) return 1;
+  if (b.row_lo != LBM_EDGE_PERIODIC || b.row_hi != LBM_EDGE_PERIODIC || !col_ok(b.col_lo) || !col_ok(b.col_hi)) return 1;
+  if (bc_mixed_axis(make_bc(&b)) || C < 64 || R < 6 * D + 8) return 1;
+  if (sv->model == LBM_MODEL_KBC && D > 2) return 1;
+  const double* src = sv->lat[sv->cur];
+  double* dst = sv->lat[sv->cur ^ 1];
+  const int Rb = 4 * D;
+  lbm_geom sg{Rb, C, 0, sv->seam_plane};
+  const size_t spitch = (size_t)sv->g.plane_stride * sizeof(double), dpitch = (size_t)sv->seam_plane * sizeof(double);
+  const size_t half = (size_t)2 * D * C * sizeof(double);
+  hipStream_t ss = sv->seam_st;
+  LBM_CHECK_HIP(hipEventRecord(sv->ev_seam_fork, sv->st));
+  LBM_CHECK_HIP(hipStreamWaitEvent(ss, sv->ev_seam_fork, 0));
+  // rows [0, 2D) -> small rows [0, 2D); rows [R - 2D, R) -> small rows [2D, 4D)
+  LBM_CHECK_HIP(hipMemcpy2DAsync(sv->seam[0], dpitch, src, spitch, half, 9, hipMemcpyDeviceToDevice, ss));
+  LBM_CHECK_HIP(hipMemcpy2DAsync(sv->seam[0] + (size_t)2 * D * C, dpitch, src + (size_t)(R - 2 * D) * C, spitch, half, 9,
+                                 hipMemcpyDeviceToDevice, ss));
+  int cur = 0, rc = LBM_OK;
+  for (int k = 0; k < D && !rc; ++k, cur ^= 1)
+    rc = sv->model == LBM_MODEL_BGK
+             ? lbm_bgk_stream_collide(sv->seam[cur ^ 1], sv->seam[cur], &sg, &sv->bc, &sv->bgk, 0, Rb, nullptr, nullptr, ss)
+             : lbm_kbc_stream_collide(sv->seam[cur ^ 1], sv->seam[cur], &sg, &sv->bc, &sv->kbc, 0, Rb, nullptr, nullptr, ss);
+  if (rc) return rc;
+  const size_t part = (size_t)D * C * sizeof(double);
+  LBM_CHECK_HIP(hipMemcpy2DAsync(dst, spitch, sv->seam[cur], dpitch, part, 9, hipMemcpyDeviceToDevice, ss));
+  LBM_CHECK_HIP(hipMemcpy2DAsync(dst + (size_t)(R - D) * C, spitch, sv->seam[cur] + (size_t)3 * D * C, dpitch, part, 9,
+                                 hipMemcpyDeviceToDevice, ss));
+  LBM_CHECK_HIP(hipEventRecord(sv->ev_seam_join, ss));
+  // the far rows: plain multi-step window (walls on the columns included), no pressure rows
+  lbm_bc far = sv->bc;
+  far.pressure_rows = 0;
+  rc = sv->model == LBM_MODEL_BGK
+           ? bgk_stream_collide_xn_ref(dst, src, &sv->g, &far, &sv->bgk, D, D, R - D, sv->st)
+           : kbc_stream_collide_x2_ref(dst, src, &sv->g, &far, &sv->kbc, D, R - D, sv->st);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipStreamWaitEvent(sv->st, sv->ev_seam_join, 0));
+  return LBM_OK;
+}
+
 // periodic or wall-bounded block without per-step observers: steps can be fused several per launch
 static bool solver_can_fuse_steps(const lbm_solver* sv) {
   const lbm_bc& b = sv->bc;
@@ -283,9 +362,27 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
       if (rc) return rc;
       if (sv->model == LBM_MODEL_KBC && depth > 4) depth = 4;
       sv->cur ^= 1;
+      ++sv->blocks;
       sv->steps += depth;
       i += depth;
       continue;
+    }
+    if (sv->post && sv->bc.pressure_rows && !sv->ibm && depth >= 2 && tuning("pressure_depth", sv->model == LBM_MODEL_KBC ? 2 : 5) >= 2) {
+      int d = tuning("pressure_depth", sv->model == LBM_MODEL_KBC ? 2 : 5);
+      if (d > depth) d = depth;
+      if (d > kSeamMaxDepth) d = kSeamMaxDepth;
+      if (sv->model == LBM_MODEL_KBC && d > 2) d = 2;
+      while (d >= 2 && sv->g.R < 6 * d + 8) --d;
+      const int rc = d >= 2 ? solver_pressure_block(sv, d) : 1;
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        sv->cur ^= 1;
+        ++sv->blocks;
+        sv->steps += d;
+        sv->have_moments = false;
+        i += d;
+        continue;
+      }
     }
     if (sv->post && sv->ibm && sv->side && sv->model == LBM_MODEL_BGK && depth >= 2 && tuning("ibm_depth", 5) >= 2) {
       const int d = depth < tuning("ibm_depth", 5) ? depth : tuning("ibm_depth", 5);
@@ -293,6 +390,7 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
       if (rc < 0) return rc;
       if (rc == 0) {
         sv->cur ^= 1;
+        ++sv->blocks;
         sv->steps += d;
         sv->have_moments = false;  // rho, u hold the ROI rows of the last step only
         i += d;
@@ -362,6 +460,8 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
   sv->guo_b = guo_b;
   return LBM_OK;
 }
+
+long long lbm_solver_block_launches(const lbm_solver* sv) { return sv ? sv->blocks : -1; }
 
 int lbm_solver_sync(lbm_solver* sv) {
   LBM_REQUIRE(sv, "lbm_solver_sync: NULL solver");

@@ -715,7 +715,8 @@ __host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 :
 template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
-    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0) {
+    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0,
+    int chunk_stride = 0) {
   constexpr int W = sw_strip_width(D, sw_full_strips<Model>::value);  // output columns per wave
   // workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th block.  xcd_group = G > 0: consecutive
   // blocks of one XCD take G consecutive strip groups, so the 128-B lines that neighbouring strips
@@ -728,7 +729,9 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)
   const int wave = blk * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wave >= n_waves) return;
   const int strip = strip0 + wave % strips, chunk = wave / strips;  // strips = those of this launch, from strip0 on
-  const int R0 = row_begin + chunk * rows_per_chunk;
+  // chunk_stride > rows_per_chunk: the chunks are row ranges apart from each other (both edge-row
+  // ranges of a slab in one launch: chunk 0 = [row_begin, +rows), chunk 1 = [row_begin + stride, +rows))
+  const int R0 = row_begin + chunk * (chunk_stride > 0 ? chunk_stride : rows_per_chunk);
   const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
   // this lane's column at every level; lanes D-1 .. 63-(D-1) hold valid level-D values
   int c = strip * W - (D - 1) + lane;

@@ -15,6 +15,13 @@ void set_error(const char* fmt, ...);
 int tuning(const char* key, int dflt);
 // capi_ibm.hip: one-wave kernel on `st` that ends once the last lbm_ibm_step's workgroup is resident
 int ibm_gate(lbm_ibm* ib, hipStream_t st);
+// capi_kbc.hip: 2 time steps per launch through the sliding window with the REFERENCE-ORDER KBC model
+// (lattices with pressure rows keep that order: solver_pressure_block); rows [row_begin, row_end)
+int kbc_stream_collide_x2_ref(double* p_new, const double* p_old, const lbm_geom* g, const lbm_bc* bc,
+                              const lbm_kbc_params* prm, int row_begin, int row_end, hipStream_t st);
+// capi_bgk.hip: lbm_bgk_stream_collide_xn pinned to the reference operation order
+int bgk_stream_collide_xn_ref(double* p_new, const double* p_old, const lbm_geom* g, const lbm_bc* bc,
+                              const lbm_bgk_params* prm, int n_steps, int row_begin, int row_end, hipStream_t st);
 // NumPy .npy (v1.0, little-endian f64, C order) writer shared by the snapshot objects
 int write_npy(const char* path, const double* data, const std::vector<long>& shape);
 

@@ -294,7 +294,19 @@ int sw_launch_walls(double* pn, const double* po, const Geom& g, const Model& m,
 template <class Model>
 int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const lbm_geom* lg,
                              const lbm_bc* lbc, const Model& m, int depth, int row_begin,
-                             int row_end, hipStream_t st, int default_waves = 4) {
+                             int row_end, hipStream_t st, int default_waves = 4, int second_begin = -1) {
+  // second_begin >= 0: ALSO rows [second_begin, second_begin + (row_end - row_begin)) in the same
+  // launch (the two edge-row ranges of a slab: one dispatch instead of two serialised ones)
+  if (second_begin >= 0) {
+    LBM_REQUIRE(lg && second_begin >= row_end && second_begin + (row_end - row_begin) <= lg->R && row_end - row_begin <= 192,
+                "%s: second row range [%d, +%d) must follow the first and fit the lattice", fn, second_begin, row_end - row_begin);
+    const Bc b2 = make_bc(lbc);
+    if (bc_needs_edge_pass(b2)) {  // wall-carrying launches keep their frame / interior split: two calls
+      int rc2 = launch_stream_collide_sw(fn, pn, po, lg, lbc, m, depth, row_begin, row_end, st, default_waves);
+      if (rc2) return rc2;
+      return launch_stream_collide_sw(fn, pn, po, lg, lbc, m, depth, second_begin, second_begin + (row_end - row_begin), st, default_waves);
+    }
+  }
   int rc = validate_geom_bc(fn, lg, lbc);
   if (rc) return rc;
   LBM_REQUIRE(pn && po && pn != po, "%s: NULL or aliased lattices", fn);
@@ -327,7 +339,10 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
     }
     if (rpc > nrows) rpc = nrows;
     n_waves = strips * ((nrows + rpc - 1) / rpc);
+    if (second_begin >= 0) rpc = nrows, n_waves = 2 * strips;  // one chunk per range
   };
+  const int chunk_stride = second_begin >= 0 ? second_begin - row_begin : 0;
+  const int row_end_k = second_begin >= 0 ? second_begin + nrows : row_end;  // the kernel clips chunks at this row
   if (walls) {  // wall-carrying variant: 2-wave blocks only (no register cap: 4-wave blocks, capped at
                 // 168 / 256 VGPRs, spill up to 1300 registers with the fix-ups in)
 #define LBM_SWBC(DV)                                                                              \
@@ -347,8 +362,8 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   if (depth == DV && waves == WV) {                                                               \
     plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV);                         \
     const dim3 grid((n_waves + WV - 1) / WV);                                                     \
-    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0)); \
-    else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end, rpc, strips, n_waves, tuning("sw_xcd", 0));   \
+    if (nt) LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, true>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end_k, rpc, strips, n_waves, tuning("sw_xcd", 0), Bc{}, 0, chunk_stride); \
+    else LBM_KLAUNCH((k_stream_collide_sw<Model, DV, WV, false>), grid, dim3(64 * WV), 0, st, pn, po, g, m, row_begin, row_end_k, rpc, strips, n_waves, tuning("sw_xcd", 0), Bc{}, 0, chunk_stride);   \
   } else
   LBM_SW(2, 4) LBM_SW(3, 4) LBM_SW(4, 4) LBM_SW(5, 4) LBM_SW(6, 4)
   LBM_SW(2, 1) LBM_SW(3, 1) LBM_SW(4, 1) LBM_SW(2, 2) LBM_SW(3, 2) LBM_SW(4, 2) LBM_SW(5, 2) LBM_SW(6, 2) {

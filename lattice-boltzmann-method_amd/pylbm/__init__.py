@@ -92,6 +92,7 @@ def load_library(path=LIB_PATH):
     lib = ct.CDLL(path)
     lib.lbm_last_error_string.restype = ct.c_char_p
     lib.lbm_default_plane_pad.restype = ct.c_longlong
+    lib.lbm_solver_block_launches.restype = ct.c_longlong
     return lib
 
 
@@ -119,7 +120,7 @@ class Lib:
         return int(self.raw.lbm_default_plane_pad(R, C))
 
     def reset_tuning(self):
-        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd", b"kbc_fast", b"kbc_depth", b"bgk_fast", b"cg_strip", b"cg_rows", b"cg_split", b"sw_split", b"solver_depth_walls", b"ibm_depth", b"ibm_gate", b"bgk_fast_delta"):
+        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd", b"kbc_fast", b"kbc_depth", b"bgk_fast", b"cg_strip", b"cg_rows", b"cg_split", b"sw_split", b"solver_depth_walls", b"ibm_depth", b"ibm_gate", b"bgk_fast_delta", b"pressure_depth", b"halo_grid"):
             self.set_tuning(k, -1)
 
 

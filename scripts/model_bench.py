@@ -161,6 +161,18 @@ if __name__ == "__main__":
                              pylbm.BgkParams(1.2, 0), bc=bc)
             lib.set_tuning(b"solver_depth", -1)
             lib.set_tuning(b"solver_depth_walls", -1)
+    if "pressure" in which:   # Poiseuille channel at config-2 size: pressure-periodic rows, bounce-back columns
+        from math import sqrt
+        omega = 1.0 / (sqrt(3.0 / 16.0) + 0.5)
+        H = W = int(os.environ.get("LBM_PRESSURE_SIZE", "8192"))
+        grad = 8.0 * (1.0 / 3.0) * (1.0 / omega - 0.5) * 0.1 / (W * W)
+        bc = pylbm.Bc(col_lo=pylbm.EDGE_BOUNCE_BACK, col_hi=pylbm.EDGE_BOUNCE_BACK, pressure_rows=1,
+                      rho_inlet=1.0 + 3.0 * (H - 1) * grad, rho_outlet=1.0)
+        for depth in os.environ.get("LBM_PRESSURE_DEPTH", "5,3,1").split(","):
+            lib.set_tuning(b"pressure_depth", int(depth))
+            bench_single(pylbm.MODEL_BGK, "BGK Poiseuille channel (pressure rows + bounce-back columns, incompressible), %s step(s) per block" % depth,
+                         H, W, pylbm.BgkParams(omega, 1), bc=bc)
+        lib.set_tuning(b"pressure_depth", -1)
     if "kbc" in which:
         for depth in os.environ.get("LBM_KBC_DEPTH", "3").split(","):
             lib.set_tuning(b"kbc_depth", int(depth))

@@ -1,0 +1,110 @@
+"""Pressure-periodic rows (test/horizontal_poiseuille_test.cpp:25-45, test/ulbm_poiseuille.cpp:36-58,
+test/specular_boundary_test.cpp, test/gravity_test.cpp) at multi-step speed: lbm_solver_step advances D
+steps per block -- rows at least D away from the virtual rows 0 / R-1 through the D-step window, the 2 D
+rows on either side of the seam in single steps on a small periodic lattice (capi_solver.hip
+solver_pressure_block).  Same kernels per node as single steps, so every depth must give the same BITS as
+"pressure_depth" = 1 (one step per launch), which in turn is held to the oracle / the unmodified
+reference mains elsewhere (test_gpu_bgk.py, test_gpu_presets.py, test_gpu_kbc.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+import pylbm  # noqa: E402
+from gpu_util import bits_equal, ulp_diff  # noqa: E402
+from pyoracle import hpt_params  # noqa: E402
+
+W9 = np.array([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = pylbm.Lib()
+    assert lib.device_count() >= 1
+    return lib
+
+
+def perturbed_rest(H, W, seed):
+    """rest state + a smooth perturbation, so that a wrong row / column shows up at once"""
+    rng = np.random.default_rng(seed)
+    f = np.empty((H, W, 9))
+    f[...] = W9
+    return f * (1 + 0.01 * rng.standard_normal((H, W, 9)))
+
+
+def run(lib, model, H, W, prm, bc, f0, n, depth, moments=None):
+    lib.set_tuning(b"pressure_depth", depth)
+    sv = pylbm.Solver(lib, model, H, W, prm, bc=bc)
+    sv.set_f(f0)
+    if moments is not None:
+        sv.set_moments(*moments)
+    sv.step(n)
+    f = sv.get_f()
+    sv.close()
+    lib.set_tuning(b"pressure_depth", -1)
+    return f
+
+
+@pytest.mark.parametrize("case", ["poiseuille_bb", "specular", "gravity", "periodic_cols"])
+@pytest.mark.parametrize("H,W", [(64, 64), (96, 150), (257, 200)])
+def test_bgk_pressure_blocks_equal_single_steps(lib, case, H, W):
+    p = hpt_params(H, W, 0)
+    bc = pylbm.Bc(pressure_rows=1, rho_inlet=p.rho_inlet, rho_outlet=p.rho_outlet)
+    prm = pylbm.BgkParams(p.omega, 1)
+    if case == "poiseuille_bb":
+        bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+    elif case == "specular":                      # specular_boundary_test.cpp: compressible equilibrium
+        bc.col_lo = bc.col_hi = pylbm.EDGE_SPECULAR
+        prm = pylbm.BgkParams(p.omega, 0)
+    elif case == "gravity":                       # gravity_test.cpp: body force, rho_in = rho_out
+        bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+        bc.rho_inlet = bc.rho_outlet = 1.0
+        prm = pylbm.BgkParams(p.omega, 1, force=(-0.0003, 0.0))
+    f0 = perturbed_rest(H, W, seed=H + W)
+    n = 23                                        # first step singly, then 5-blocks and a remainder
+    want = run(lib, pylbm.MODEL_BGK, H, W, prm, bc, f0, n, 1)
+    for depth in (2, 3, 5):
+        if H < 6 * depth + 8:
+            continue
+        got = run(lib, pylbm.MODEL_BGK, H, W, prm, bc, f0, n, depth)
+        assert bits_equal(got, want), (case, H, W, depth, ulp_diff(got, want))
+    got = run(lib, pylbm.MODEL_BGK, H, W, prm, bc, f0, n, -1)   # the default
+    assert bits_equal(got, want), (case, H, W, "default", ulp_diff(got, want))
+
+
+def test_bgk_pressure_blocks_vs_oracle_config1(lib, oracle):
+    """BASELINE config 1 (256 x 64) through 5-step blocks == the oracle bit for bit, and the blocks
+    really ran (the default depth is 5; a silent fallback to single steps would pass otherwise)"""
+    p = hpt_params(256, 64, 203, check_convergence=0)
+    bc = pylbm.Bc(col_lo=pylbm.EDGE_BOUNCE_BACK, col_hi=pylbm.EDGE_BOUNCE_BACK, pressure_rows=1,
+                  rho_inlet=p.rho_inlet, rho_outlet=p.rho_outlet)
+    f0 = np.empty((256, 64, 9))
+    f0[...] = W9
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, 256, 64, pylbm.BgkParams(p.omega, 1), bc=bc)
+    sv.set_f(f0)
+    assert lib.raw.lbm_solver_block_launches(sv.h) == 0
+    sv.step(203)
+    assert lib.raw.lbm_solver_block_launches(sv.h) == 41     # 1 single + 40 x 5 + one block of 2
+    f = sv.get_f()
+    sv.close()
+    o = oracle.hpt_run(p)
+    assert bits_equal(f, o["f"]), ulp_diff(f, o["f"])
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (128, 128)])
+def test_kbc_pressure_blocks_equal_single_steps(lib, H, W):
+    """ulbm_poiseuille preset: KBC + pressure rows + bounce-back columns, 2 steps per block (the far rows
+    through the reference-order 2-step window)"""
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    rin = 3.0 * (H - 1) * (8.0 * nu * 0.05 / (W * W)) + 1.0
+    bc = pylbm.Bc(col_lo=pylbm.EDGE_BOUNCE_BACK, col_hi=pylbm.EDGE_BOUNCE_BACK, pressure_rows=1,
+                  rho_inlet=rin, rho_outlet=1.0)
+    f0 = np.zeros((H, W, 9))
+    mom = (np.ones((H, W)), np.zeros((H, W, 2)))
+    want = run(lib, pylbm.MODEL_KBC, H, W, pylbm.KbcParams(s2), bc, f0, 12, 1, mom)
+    got = run(lib, pylbm.MODEL_KBC, H, W, pylbm.KbcParams(s2), bc, f0, 12, 2, mom)
+    assert bits_equal(got, want), (H, W, ulp_diff(got, want))
+    got = run(lib, pylbm.MODEL_KBC, H, W, pylbm.KbcParams(s2), bc, f0, 12, -1, mom)
+    assert bits_equal(got, want), (H, W, "default", ulp_diff(got, want))
