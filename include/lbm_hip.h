@@ -435,6 +435,51 @@ int lbm_ring_bgk_step_ibm(lbm_ring* rg, double* dst, const double* src, const lb
                           const lbm_bgk_params* prm, int edge_rows, lbm_ibm* ib, double guo_a,
                           double guo_b, double* rho, double* u, lbm_stream_t main);
 
+/* ---- config 5 over slabs at multi-step speed: BGK slab with an immersed boundary anywhere, also across
+ * a seam (cylinder_test.cpp:88-164 / ibm.cpp:158-190 over the block binding of decompose_domain.cpp:181-187).
+ * Per block of D steps: a band of global rows [q0 - 2D, q1 + 2D) around the ROI advances D forced single
+ * steps in a compact lattice of its own, replicated on every slab that owns valid band rows [q0 - D,
+ * q1 + D); all other rows take the D-step window.  Across a seam inside the band the two co-owners swap
+ * the band's D outermost rows instead of the ordinary halo (same size: 9 D rows of C doubles).  The
+ * transport belongs to the caller (lbm_ring_bgk_block_ibm below uses RCCL): *_compute fills the two send
+ * buffers, *_finish consumes the two receive buffers.  x, y: GLOBAL marker coordinates; slab: geometry with
+ * ghost >= depth; the slab's rows start at global row slab_row0 of a domain of rows_global rows whose
+ * physical edges are bc_global (seams become HALO).  Results equal the single-block solver bit for bit. */
+typedef struct lbm_slab_ibm lbm_slab_ibm;
+int lbm_slab_ibm_create(lbm_slab_ibm** out, const lbm_geom* slab, int slab_row0, int rows_global,
+                        const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth, const double* x,
+                        const double* y, int n_markers, int m_max, double guo_a, double guo_b);
+int lbm_slab_ibm_destroy(lbm_slab_ibm* sl);
+/* owner: this slab runs the band chain; straddle_*: the band's valid rows reach into that neighbour
+ * (a co-owner); [b0, b1): global band rows.  Any output may be NULL. */
+int lbm_slab_ibm_info(const lbm_slab_ibm* sl, int* owner, int* straddle_prev, int* straddle_next, int* b0, int* b1);
+long long lbm_slab_ibm_msg_doubles(const lbm_slab_ibm* sl); /* per side per block */
+/* once, on the initial post-collision state: ordinary seams exchange the complete D-row halo, co-owners
+ * all their owned band rows (side 0 = previous slab, 1 = next; counts in doubles) */
+int lbm_slab_ibm_prime_counts(const lbm_slab_ibm* sl, int side, long long* send, long long* recv);
+int lbm_slab_ibm_prime_pack(lbm_slab_ibm* sl, const double* lattice, double* send_prev, double* send_next, lbm_stream_t s);
+int lbm_slab_ibm_prime_finish(lbm_slab_ibm* sl, double* lattice, const double* recv_prev, const double* recv_next, lbm_stream_t s);
+/* the driver's FIRST iteration (cylinder_test.cpp:103-127 on the initial state) instead of prime_finish:
+ * prime_pack is then called on the PRE-collision lattice `pre`, whose ghost rows are filled here; `post`
+ * = collision of every row + forcing and source on the band rows, ghost rows current, band primed */
+int lbm_slab_ibm_start_finish(lbm_slab_ibm* sl, double* post, double* pre, const double* recv_prev,
+                              const double* recv_next, lbm_stream_t s);
+/* one block of `depth` steps: dst from src (ghost rows of src complete and current), messages packed */
+int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src, double* send_prev,
+                               double* send_next, lbm_stream_t s);
+int lbm_slab_ibm_block_finish(lbm_slab_ibm* sl, double* dst, const double* recv_prev, const double* recv_next, lbm_stream_t s);
+int lbm_slab_ibm_surface_force(lbm_slab_ibm* sl, double* out2, lbm_stream_t s); /* owners: F_s of the last step */
+/* n_rows complete rows (all 9 populations) between two lattices of equal column count; rows in owned-row
+ * indices, ghost rows allowed where the geometry has them */
+int lbm_rows_copy(double* dst, const lbm_geom* dg, int dst_row, const double* src, const lbm_geom* sg,
+                  int src_row, int n_rows, lbm_stream_t s);
+/* the same over the slab ring: priming exchange, then one block per call (non-owners: the overlapped
+ * lbm_ring_bgk_step schedule; owners: band chain beside the far rows, exchange behind both) */
+int lbm_ring_ibm_prime(lbm_ring* rg, lbm_slab_ibm* sl, double* lattice, lbm_stream_t main);
+int lbm_ring_ibm_start(lbm_ring* rg, lbm_slab_ibm* sl, double* post, double* pre, lbm_stream_t main);
+int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const double* src, int edge_rows,
+                           lbm_stream_t main);
+
 /* ---- population links between lattices on one GPU (multi-block topologies) -----------------------
  * The reference glues blocks by slice assignments after advect (test/decompose_domain.cpp:181-187;
  * test/decompose_domain_loop.cpp:235-261, plus its slice-assignment walls :173-231): here a table of

@@ -12,6 +12,7 @@
 
 #include "d2q9.hpp"
 #include "internal.hpp"
+#include "slab_ibm.hpp"
 
 namespace {
 
@@ -450,6 +451,93 @@ int lbm_ring_last_timing(lbm_ring* rg, double* out4) {
   out4[2] = inner;
   out4[3] = span_x > span_m ? span_x : span_m;
   return LBM_OK;
+}
+
+// ---- config 5 over slabs at multi-step speed (capi_slab_ibm.hip holds the per-rank engine) ----------------
+// One send + one recv per neighbour in one RCCL group on the ring's edge stream, ordered after `after`.
+static int ring_sendrecv(lbm_ring* rg, const double* send_prev, size_t n_send_prev, double* recv_prev, size_t n_recv_prev,
+                         const double* send_next, size_t n_send_next, double* recv_next, size_t n_recv_next,
+                         hipStream_t after) {
+  LBM_CHECK_HIP(hipEventRecord(rg->main_done, after));
+  LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+  LBM_CHECK_NCCL(g_rccl.GroupStart());
+  if (rg->next >= 0 && n_send_next) LBM_CHECK_NCCL(g_rccl.Send(send_next, n_send_next, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  if (rg->prev >= 0 && n_send_prev) LBM_CHECK_NCCL(g_rccl.Send(send_prev, n_send_prev, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->prev >= 0 && n_recv_prev) LBM_CHECK_NCCL(g_rccl.Recv(recv_prev, n_recv_prev, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->next >= 0 && n_recv_next) LBM_CHECK_NCCL(g_rccl.Recv(recv_next, n_recv_next, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  LBM_CHECK_NCCL(g_rccl.GroupEnd());
+  LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+  LBM_CHECK_HIP(hipStreamWaitEvent(after, rg->edge_done, 0));
+  return LBM_OK;
+}
+
+// the priming exchange of lbm_slab_ibm_prime_* (once per run: its buffers are allocated here and freed
+// again; co-owners swap all their owned band rows, which the ring's block-sized buffers cannot hold)
+static int ring_ibm_prime(lbm_ring* rg, lbm_slab_ibm* sl, double* lattice, double* post, lbm_stream_t main_s);
+int lbm_ring_ibm_prime(lbm_ring* rg, lbm_slab_ibm* sl, double* lattice, lbm_stream_t main_s) {
+  return ring_ibm_prime(rg, sl, lattice, nullptr, main_s);
+}
+// the driver's first iteration over the ring: `pre` = pre-collision state (its ghost rows are filled
+// here), `post` receives the post-collision state incl. forcing and source, ghost rows current
+int lbm_ring_ibm_start(lbm_ring* rg, lbm_slab_ibm* sl, double* post, double* pre, lbm_stream_t main_s) {
+  LBM_REQUIRE(post, "lbm_ring_ibm_start: NULL argument");
+  return ring_ibm_prime(rg, sl, pre, post, main_s);
+}
+static int ring_ibm_prime(lbm_ring* rg, lbm_slab_ibm* sl, double* lattice, double* post, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && sl && lattice, "lbm_ring_ibm_prime: NULL argument");
+  LBM_REQUIRE((!sl->has_prev || rg->prev >= 0) && (!sl->has_next || rg->next >= 0),
+              "lbm_ring_ibm_prime: the slab has a neighbour the ring does not know");
+  LBM_REQUIRE(rg->g.ghost == sl->D, "lbm_ring_ibm_prime: ring with %d ghost rows, blocks of %d steps", rg->g.ghost, sl->D);
+  hipStream_t main = as_stream(main_s);
+  long long cnt[2][2];  // [side][send / recv]
+  for (int side = 0; side < 2; ++side) {
+    int rc = lbm_slab_ibm_prime_counts(sl, side, &cnt[side][0], &cnt[side][1]);
+    if (rc) return rc;
+  }
+  double* buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipError_t e = hipSuccess;
+  for (int side = 0; side < 2; ++side)
+    for (int k = 0; k < 2; ++k)
+      if (cnt[side][k] > 0 && e == hipSuccess) e = hipMalloc(&buf[side][k], (size_t)cnt[side][k] * sizeof(double));
+  int rc = LBM_OK;
+  if (e != hipSuccess) {
+    set_error("lbm_ring_ibm_prime: %s", hipGetErrorString(e));
+    rc = LBM_ERR_HIP;
+  }
+  if (!rc) rc = lbm_slab_ibm_prime_pack(sl, lattice, buf[0][0], buf[1][0], main_s);
+  if (!rc) rc = ring_sendrecv(rg, buf[0][0], (size_t)cnt[0][0], buf[0][1], (size_t)cnt[0][1], buf[1][0], (size_t)cnt[1][0],
+                              buf[1][1], (size_t)cnt[1][1], main);
+  if (!rc) rc = post ? lbm_slab_ibm_start_finish(sl, post, lattice, buf[0][1], buf[1][1], main_s)
+                     : lbm_slab_ibm_prime_finish(sl, lattice, buf[0][1], buf[1][1], main_s);
+  if (!rc && hipStreamSynchronize(main) != hipSuccess) {
+    set_error("lbm_ring_ibm_prime: stream synchronisation failed");
+    rc = LBM_ERR_HIP;
+  }
+  for (int side = 0; side < 2; ++side)
+    for (int k = 0; k < 2; ++k)
+      if (buf[side][k]) (void)hipFree(buf[side][k]);
+  return rc;
+}
+
+// One block of sl->D steps of a BGK slab in the ring.  Slabs without valid band rows run the overlapped
+// schedule of lbm_ring_bgk_step (edge rows -> exchange of complete ghost rows beside the interior);
+// (co-)owners run the band chain beside their far rows and exchange behind both -- the band chain
+// (D dependent forced steps, latency-bound) is their critical path either way.
+int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const double* src, int edge_rows,
+                           lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && sl && dst && src, "lbm_ring_bgk_block_ibm: NULL argument");
+  LBM_REQUIRE(rg->g.R == sl->g.R && rg->g.C == sl->g.C && rg->g.ghost == sl->g.ghost && rg->g.ghost == sl->D,
+              "lbm_ring_bgk_block_ibm: ring and slab geometries differ (ghost rows must equal the block depth)");
+  LBM_REQUIRE((!sl->has_prev || rg->prev >= 0) && (!sl->has_next || rg->next >= 0),
+              "lbm_ring_bgk_block_ibm: the slab has a neighbour the ring does not know");
+  if (!sl->owner) return lbm_ring_bgk_step(rg, dst, src, &sl->bc_global, &sl->prm, sl->D, edge_rows, main_s);
+  hipStream_t main = as_stream(main_s);
+  int rc = lbm_slab_ibm_block_compute(sl, dst, src, rg->send_prev, rg->send_next, main_s);
+  if (rc) return rc;
+  const size_t msg = (size_t)lbm_slab_ibm_msg_doubles(sl);
+  rc = ring_sendrecv(rg, rg->send_prev, msg, rg->recv_prev, msg, rg->send_next, msg, rg->recv_next, msg, main);
+  if (rc) return rc;
+  return lbm_slab_ibm_block_finish(sl, dst, rg->recv_prev, rg->recv_next, main_s);
 }
 
 // make `main` wait for an exchange enqueued with lbm_ring_exchange (initial ghost fill)

@@ -1,18 +1,25 @@
 // Flow past an immersed-boundary cylinder (BASELINE config 5, test/cylinder_test.cpp) slab-decomposed
 // along the streamwise direction r over the GPUs of one node: a CHAIN of slabs -- the global rows 0
 // and Rg-1 are the anti-bounce-back velocity inlet / outlet (:135-154), the columns are specular
-// walls (:157-163) -- with the cylinder owned by one slab (lbm_ibm_create_slab).  One ghost row,
-// 3 populations per side per step (the block binding of test/decompose_domain.cpp:181-187), one
-// packed message per neighbour, exchange overlapped with the interior rows AND the forcing.
-// C++ host on lbm_ring_bgk_step_ibm; one process per GPU.
+// walls (:157-163).  The cylinder sits where SURVEY 8(d) puts it: centre at (rows/4, cols/2) -- on 8
+// slabs of 2048 rows its ROI STRADDLES the seam at row 4096.  Time advances in blocks of D = 5 steps
+// (lbm_ring_bgk_block_ibm): slabs without boundary rows run the 5-step window with one exchange of
+// complete ghost rows per block, overlapped with their interior; the one or two slabs that own rows of
+// the band around the ROI run the band's forced single steps in a compact replica beside their far
+// rows and, across a seam inside the band, swap its outer rows instead of the halo.
+// C++ host; one process per GPU.
 //
 //   slab_ring_cylinder --spawn N [--rows R_per_gpu] [--cols C] [--steps K] [--warmup W]
-//                      [--diameter D] [--edge-rows E] [--check 1]
+//                      [--diameter D] [--centre-row r] [--depth 5] [--edge-rows E] [--check 1]
+//   slab_ring_cylinder --emulate N ...   ONE process / one GPU playing all N slabs of the chain in turn
+//                      (messages moved by device copies; per-slab time per block reported; --check 1
+//                      compares with the single-block run bit for bit -- the 8 x 2048 x 4096 layout of
+//                      BASELINE config 5 fits one MI355X several times over)
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_cylinder --id-file /tmp/x ...
 //
 // tau = 0.55 (parameters.toml), u_in = 0.04 (SURVEY 8d allows a smaller u for the benchmark), markers
-// on a circle of the given diameter with spacing ~1 centred in the middle of slab N/4 (SURVEY 8e:
-// "place the cylinder away from seams and assert") and at column C/2, generated deterministically.
+// on a circle of the given diameter with spacing ~1, generated deterministically.
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -23,15 +30,15 @@
 namespace {
 
 struct Args {
-  int rows = 2048, cols = 4096, steps = 50, warmup = 5, edge_rows = 8, check = 0, diameter = 300;
+  int rows = 2048, cols = 4096, steps = 50, warmup = 5, edge_rows = 32, check = 0, diameter = 300;
+  int depth = 5, centre_row = -1, emulate = 0;
   std::string id_file;
 };
 const double kTau = 0.55, kUin = 0.04, kGuoA = 1.0 / 3.0, kGuoB = 1.0 / 9.0;  // cylinder_test.cpp:66-67
 
-void cylinder_markers(int Rg, int C, int R, int world, int diameter, std::vector<double>& x,
-                      std::vector<double>& y, int& owner) {
-  owner = world / 4;
-  const double cx = owner * (double)R + R / 2.0, cy = C / 2.0, rad = diameter / 2.0;
+void cylinder_markers(int Rg, int C, int centre_row, int diameter, std::vector<double>& x, std::vector<double>& y) {
+  // centre at (rows / 4, cols / 2) unless told otherwise
+  const double cx = (centre_row >= 0 ? centre_row : Rg / 4) + 0.37, cy = C / 2.0 + 0.21, rad = diameter / 2.0;
   const int m = (int)std::lround(3.14159265358979323846 * diameter);
   x.resize(m);
   y.resize(m);
@@ -40,7 +47,6 @@ void cylinder_markers(int Rg, int C, int R, int world, int diameter, std::vector
     x[i] = cx + rad * std::cos(t);
     y[i] = cy + rad * std::sin(t);
   }
-  (void)Rg;
 }
 
 lbm_bc global_bc() {
@@ -76,75 +82,71 @@ double* uniform_inflow(int R, int C, int G) {
 
 int run_rank(const Args& a, int rank, int world, int local_rank) {
   check(lbm_set_device(local_rank), "lbm_set_device");
-  const int R = a.rows, C = a.cols, Rg = R * world, G = 1;
+  const bool rehearse = false;
+  const int vr = rank, vw = world;
+  const int D = a.depth, R = a.rows, C = a.cols, Rg = R * vw, G = D;
   lbm_geom g{R, C, G, 0};
   lbm_bgk_params prm{};
   prm.omega = 1.0 / kTau;
   prm.incompressible = 0;
   prm.delta_form = 1;  // :123-125
-  lbm_bc bc = global_bc(), slab_bc = bc;
-  if (rank > 0) slab_bc.row_lo = LBM_EDGE_HALO;
-  if (rank < world - 1) slab_bc.row_hi = LBM_EDGE_HALO;
+  lbm_bc bc = global_bc();
 
   std::vector<double> mx, my;
-  int owner = 0;
-  cylinder_markers(Rg, C, R, world, a.diameter, mx, my, owner);
-  lbm_ibm* ib = nullptr;
-  if (rank == owner)
-    check(lbm_ibm_create_slab(&ib, mx.data(), my.data(), (int)mx.size(), 5, R, C, owner * R), "lbm_ibm_create_slab");
+  cylinder_markers(Rg, C, a.centre_row, a.diameter, mx, my);
+  lbm_slab_ibm* sl = nullptr;
+  check(lbm_slab_ibm_create(&sl, &g, vr * R, Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB),
+        "lbm_slab_ibm_create");
+  int owner = 0, sp = 0, sn = 0, b0 = 0, b1 = 0;
+  check(lbm_slab_ibm_info(sl, &owner, &sp, &sn, &b0, &b1), "lbm_slab_ibm_info");
 
   unsigned char id[128];
   share_unique_id(id, rank, world, a.id_file);
   lbm_ring* ring = nullptr;
-  check(lbm_ring_create(&ring, id, rank, world, &g, /*periodic=*/0), "lbm_ring_create");
+  check(lbm_ring_create(&ring, id, rank, world, &g, /*periodic=*/rehearse ? 1 : 0), "lbm_ring_create");
 
   const size_t n = (size_t)R * C, plane = (size_t)(R + 2 * G) * C;
-  double *lat[2], *rho, *u;
+  double* lat[2];
   double* pre = uniform_inflow(R, C, G);
   check(lbm_malloc((void**)&lat[0], 9 * plane * 8), "lbm_malloc");
   check(lbm_malloc((void**)&lat[1], 9 * plane * 8), "lbm_malloc");
-  check(lbm_malloc((void**)&rho, n * 8), "lbm_malloc");
-  check(lbm_malloc((void**)&u, 2 * n * 8), "lbm_malloc");
   for (double* p : {lat[0], lat[1]}) check(lbm_memset(p, 0, 9 * plane * 8, nullptr), "memset");
-  // first iteration (:103-127): moments, collision in delta form, forcing + source on the owner
-  check(lbm_bgk_collide(lat[0], pre, &g, &slab_bc, &prm, rho, u, nullptr), "lbm_bgk_collide");
-  if (ib) {
-    check(lbm_ibm_force(ib, u, rho, nullptr, nullptr), "lbm_ibm_force");
-    check(lbm_ibm_add_source(ib, lat[0], &g, u, prm.omega, kGuoA, kGuoB, nullptr), "lbm_ibm_add_source");
-  }
-  check(lbm_ring_exchange(ring, lat[0], nullptr), "lbm_ring_exchange");
-  check(lbm_ring_join(ring, nullptr), "lbm_ring_join");
+  // first iteration (:103-127): moments, collision in delta form, forcing + source on the band's owners
+  check(lbm_ring_ibm_start(ring, sl, lat[0], pre, nullptr), "lbm_ring_ibm_start");
   check(lbm_stream_sync(nullptr), "sync");
   lbm_free(pre);
 
   int cur = 0;
-  auto step = [&]() {
-    check(lbm_ring_bgk_step_ibm(ring, lat[cur ^ 1], lat[cur], &bc, &prm, a.edge_rows, ib, kGuoA, kGuoB, rho, u,
-                                nullptr), "lbm_ring_bgk_step_ibm");
+  auto block = [&]() {
+    check(lbm_ring_bgk_block_ibm(ring, sl, lat[cur ^ 1], lat[cur], a.edge_rows, nullptr), "lbm_ring_bgk_block_ibm");
     cur ^= 1;
   };
-  for (int i = 0; i < a.warmup; ++i) step();
+  const int wb = (a.warmup + D - 1) / D, nb = (a.steps + D - 1) / D, steps = nb * D;
+  for (int i = 0; i < wb; ++i) block();
   check(lbm_stream_sync(nullptr), "sync");
   auto t0 = std::chrono::steady_clock::now();
-  for (int i = 0; i < a.steps; ++i) step();
+  for (int i = 0; i < nb; ++i) block();
   check(lbm_stream_sync(nullptr), "sync");
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   const double tmax = max_time_over_ranks(sec, rank, world, a.id_file);
   double Fs[2] = {0, 0};
-  if (ib) {
-    check(lbm_ibm_surface_force(ib, Fs, nullptr), "lbm_ibm_surface_force");
+  if (owner) {
+    check(lbm_slab_ibm_surface_force(sl, Fs, nullptr), "lbm_slab_ibm_surface_force");
     write_file_atomic(a.id_file + ".g" + std::to_string(rank), Fs, sizeof Fs);
   }
+  int first_owner = -1;  // every rank can tell who owns band rows: valid rows [b0 + D, b1 - D)
+  for (int r = 0; r < vw && first_owner < 0; ++r)
+    if (b0 + D < (r + 1) * R && b1 - D > r * R) first_owner = r;
 
   int bad = 0;
-  if (a.check) {
+  if (a.check && !rehearse) {
     std::vector<double> h(9 * plane), own((size_t)9 * n);
     check(lbm_memcpy_d2h(h.data(), lat[cur], h.size() * 8, nullptr), "d2h");
     check(lbm_stream_sync(nullptr), "sync");
     for (int q = 0; q < 9; ++q) std::memcpy(&own[(size_t)q * n], &h[q * plane + (size_t)G * C], n * 8);
     write_file_atomic(a.id_file + ".f" + std::to_string(rank), own.data(), own.size() * 8);
     if (rank == 0) {
-      // the same run as ONE block through the solver context (collide-first, fused steps, forcing)
+      // the same run as ONE block through the solver context (collide-first, forced blocks)
       lbm_geom gw{Rg, C, 0, 0};
       lbm_solver* sv = nullptr;
       check(lbm_solver_create(&sv, LBM_MODEL_BGK, &gw, &bc, &prm, nullptr), "lbm_solver_create");
@@ -153,7 +155,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
       check(lbm_solver_attach_ibm(sv, ibw, kGuoA, kGuoB), "lbm_solver_attach_ibm");
       double* prew = uniform_inflow(Rg, C, 0);
       check(lbm_solver_set_f_soa_dev(sv, prew), "lbm_solver_set_f_soa_dev");
-      check(lbm_solver_step(sv, 1 + a.warmup + a.steps, 0), "lbm_solver_step");
+      check(lbm_solver_step(sv, 1 + (wb + nb) * D, 0), "lbm_solver_step");
       double *cl = nullptr, *ol = nullptr;
       lbm_geom gg;
       check(lbm_solver_lattices(sv, &cl, &ol, &gg), "lbm_solver_lattices");
@@ -170,7 +172,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
       }
       double Fw[2], Fo[2];
       check(lbm_ibm_surface_force(ibw, Fw, nullptr), "lbm_ibm_surface_force");
-      wait_file(a.id_file + ".g" + std::to_string(owner), Fo, sizeof Fo);
+      wait_file(a.id_file + ".g" + std::to_string(first_owner), Fo, sizeof Fo);
       if (std::memcmp(Fw, Fo, sizeof Fw) != 0) ++bad;
       lbm_solver_destroy(sv);
       lbm_ibm_destroy(ibw);
@@ -179,21 +181,156 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   }
   if (rank == 0) {
     double Fo[2] = {0, 0};
-    if (world > 1 || ib) {
-      if (ib) std::memcpy(Fo, Fs, sizeof Fo);
-      else wait_file(a.id_file + ".g" + std::to_string(owner), Fo, sizeof Fo);
-    }
-    std::printf("{\"driver\": \"slab_ring_cylinder\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, "
-                "\"markers\": %d, \"owner_rank\": %d, \"steps\": %d, \"ms_per_step\": %.4f, \"mlups\": %.1f, "
-                "\"Fs\": [%.17g, %.17g], \"transport\": \"rccl send/recv (C++ ring)\"%s}\n",
-                world, R, C, (int)mx.size(), owner, a.steps, 1e3 * tmax / a.steps,
-                (double)Rg * C * a.steps / tmax / 1e6, Fo[0], Fo[1],
-                a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
+    if (owner) std::memcpy(Fo, Fs, sizeof Fo);
+    else if (!rehearse && first_owner >= 0 && first_owner < world) wait_file(a.id_file + ".g" + std::to_string(first_owner), Fo, sizeof Fo);
+    std::printf("{\"driver\": \"slab_ring_cylinder\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, \"global_rows\": %d, "
+                "\"markers\": %d, \"band_rows\": [%d, %d], \"first_owner_rank\": %d, \"this_rank\": {\"rank\": %d, \"owner\": %d, "
+                "\"straddle_prev\": %d, \"straddle_next\": %d}, \"steps_per_block\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
+                "\"mlups_per_gpu\": %.1f, \"mlups\": %.1f, \"Fs\": [%.17g, %.17g], \"transport\": \"rccl send/recv (C++ ring)%s\"%s}\n",
+                world, R, C, Rg, (int)mx.size(), b0, b1, first_owner, vr, owner, sp, sn, D, steps, 1e3 * tmax / steps,
+                (double)R * C * steps / tmax / 1e6, (double)R * C * world * steps / tmax / 1e6, Fo[0], Fo[1],
+                rehearse ? ", one GPU rehearsing one slab with self send/recv" : "",
+                a.check && !rehearse ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
     std::fflush(stdout);
   }
   lbm_ring_destroy(ring);
-  if (ib) lbm_ibm_destroy(ib);
-  for (double* p : {lat[0], lat[1], rho, u}) lbm_free(p);
+  lbm_slab_ibm_destroy(sl);
+  for (double* p : {lat[0], lat[1]}) lbm_free(p);
+  return bad ? 3 : 0;
+}
+
+// --emulate N: every slab of the chain in turn on ONE GPU, messages by device copies
+int run_emulated(const Args& a, int N) {
+  check(lbm_set_device(0), "lbm_set_device");
+  const int D = a.depth, R = a.rows, C = a.cols, Rg = R * N, G = D;
+  lbm_geom g{R, C, G, 0};
+  lbm_bgk_params prm{};
+  prm.omega = 1.0 / kTau;
+  prm.delta_form = 1;
+  lbm_bc bc = global_bc();
+  std::vector<double> mx, my;
+  cylinder_markers(Rg, C, a.centre_row, a.diameter, mx, my);
+  const size_t n = (size_t)R * C, plane = (size_t)(R + 2 * G) * C;
+  struct Slab {
+    lbm_slab_ibm* sl = nullptr;
+    double* lat[2] = {nullptr, nullptr};
+    double* buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [side][send / recv], sized for the priming messages
+    int owner = 0, sp = 0, sn = 0;
+    double ms = 0;
+  };
+  std::vector<Slab> S(N);
+  int b0 = 0, b1 = 0;
+  for (int r = 0; r < N; ++r) {
+    check(lbm_slab_ibm_create(&S[r].sl, &g, r * R, Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB), "lbm_slab_ibm_create");
+    check(lbm_slab_ibm_info(S[r].sl, &S[r].owner, &S[r].sp, &S[r].sn, &b0, &b1), "lbm_slab_ibm_info");
+    for (int k = 0; k < 2; ++k) {
+      check(lbm_malloc((void**)&S[r].lat[k], 9 * plane * 8), "lbm_malloc");
+      check(lbm_memset(S[r].lat[k], 0, 9 * plane * 8, nullptr), "memset");
+    }
+    for (int side = 0; side < 2; ++side) {
+      long long cs = 0, cr = 0;
+      check(lbm_slab_ibm_prime_counts(S[r].sl, side, &cs, &cr), "lbm_slab_ibm_prime_counts");
+      const long long m = lbm_slab_ibm_msg_doubles(S[r].sl);
+      check(lbm_malloc((void**)&S[r].buf[side][0], (size_t)std::max(cs, m) * 8), "lbm_malloc");
+      check(lbm_malloc((void**)&S[r].buf[side][1], (size_t)std::max(cr, m) * 8), "lbm_malloc");
+    }
+  }
+  auto deliver = [&](bool priming) {  // next's recv_prev <- my send_next; my recv_next <- next's send_prev
+    for (int r = 0; r + 1 < N; ++r) {
+      long long s_dn = lbm_slab_ibm_msg_doubles(S[r].sl), s_up = s_dn, dummy = 0;
+      if (priming) {
+        check(lbm_slab_ibm_prime_counts(S[r].sl, 1, &s_dn, &dummy), "counts");
+        check(lbm_slab_ibm_prime_counts(S[r + 1].sl, 0, &s_up, &dummy), "counts");
+      }
+      check(lbm_memcpy_d2d(S[r + 1].buf[0][1], S[r].buf[1][0], (size_t)s_dn * 8, nullptr), "d2d");
+      check(lbm_memcpy_d2d(S[r].buf[1][1], S[r + 1].buf[0][0], (size_t)s_up * 8, nullptr), "d2d");
+    }
+  };
+  {  // first iteration (:103-127) from the uniform inflow state
+    std::vector<double*> pre(N);
+    for (int r = 0; r < N; ++r) {
+      pre[r] = uniform_inflow(R, C, G);
+      check(lbm_slab_ibm_prime_pack(S[r].sl, pre[r], S[r].buf[0][0], S[r].buf[1][0], nullptr), "lbm_slab_ibm_prime_pack");
+    }
+    deliver(true);
+    for (int r = 0; r < N; ++r) {
+      check(lbm_slab_ibm_start_finish(S[r].sl, S[r].lat[0], pre[r], S[r].buf[0][1], S[r].buf[1][1], nullptr), "lbm_slab_ibm_start_finish");
+      check(lbm_stream_sync(nullptr), "sync");
+      lbm_free(pre[r]);
+    }
+  }
+  int cur = 0;
+  const int wb = (a.warmup + D - 1) / D, nb = (a.steps + D - 1) / D, steps = nb * D;
+  for (int i = 0; i < wb + nb; ++i) {
+    for (int r = 0; r < N; ++r) {  // each slab alone on the GPU: its own time per block
+      check(lbm_stream_sync(nullptr), "sync");
+      auto t0 = std::chrono::steady_clock::now();
+      check(lbm_slab_ibm_block_compute(S[r].sl, S[r].lat[cur ^ 1], S[r].lat[cur], S[r].buf[0][0], S[r].buf[1][0], nullptr), "lbm_slab_ibm_block_compute");
+      check(lbm_stream_sync(nullptr), "sync");
+      if (i >= wb) S[r].ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    deliver(false);
+    for (int r = 0; r < N; ++r) {
+      check(lbm_stream_sync(nullptr), "sync");
+      auto t0 = std::chrono::steady_clock::now();
+      check(lbm_slab_ibm_block_finish(S[r].sl, S[r].lat[cur ^ 1], S[r].buf[0][1], S[r].buf[1][1], nullptr), "lbm_slab_ibm_block_finish");
+      check(lbm_stream_sync(nullptr), "sync");
+      if (i >= wb) S[r].ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    cur ^= 1;
+  }
+  double Fs[2] = {0, 0};
+  int first_owner = -1, bad = 0;
+  for (int r = 0; r < N; ++r)
+    if (S[r].owner) {
+      double F[2];
+      check(lbm_slab_ibm_surface_force(S[r].sl, F, nullptr), "lbm_slab_ibm_surface_force");
+      if (first_owner < 0) first_owner = r, std::memcpy(Fs, F, sizeof F);
+      else if (std::memcmp(F, Fs, sizeof F) != 0) ++bad;  // co-owners hold the same forcing
+    }
+  if (a.check) {
+    lbm_geom gw{Rg, C, 0, 0};
+    lbm_solver* sv = nullptr;
+    check(lbm_solver_create(&sv, LBM_MODEL_BGK, &gw, &bc, &prm, nullptr), "lbm_solver_create");
+    lbm_ibm* ibw = nullptr;
+    check(lbm_ibm_create(&ibw, mx.data(), my.data(), (int)mx.size(), 5, Rg, C), "lbm_ibm_create");
+    check(lbm_solver_attach_ibm(sv, ibw, kGuoA, kGuoB), "lbm_solver_attach_ibm");
+    double* prew = uniform_inflow(Rg, C, 0);
+    check(lbm_solver_set_f_soa_dev(sv, prew), "lbm_solver_set_f_soa_dev");
+    check(lbm_solver_step(sv, 1 + (wb + nb) * D, 0), "lbm_solver_step");
+    double *cl = nullptr, *ol = nullptr;
+    lbm_geom gg;
+    check(lbm_solver_lattices(sv, &cl, &ol, &gg), "lbm_solver_lattices");
+    const long long ps = gg.plane_stride ? gg.plane_stride : (long long)Rg * C;
+    std::vector<double> want(n), got(n);
+    for (int q = 0; q < 9; ++q)
+      for (int r = 0; r < N; ++r) {
+        check(lbm_memcpy_d2h(want.data(), cl + q * ps + (size_t)r * n, n * 8, nullptr), "d2h");
+        check(lbm_memcpy_d2h(got.data(), S[r].lat[cur] + q * plane + (size_t)G * C, n * 8, nullptr), "d2h");
+        check(lbm_solver_sync(sv), "sync");
+        check(lbm_stream_sync(nullptr), "sync");
+        if (std::memcmp(want.data(), got.data(), n * 8) != 0) ++bad;
+      }
+    double Fw[2];
+    check(lbm_ibm_surface_force(ibw, Fw, nullptr), "lbm_ibm_surface_force");
+    if (std::memcmp(Fw, Fs, sizeof Fw) != 0) ++bad;
+    lbm_solver_destroy(sv);
+    lbm_ibm_destroy(ibw);
+    lbm_free(prew);
+  }
+  std::printf("{\"driver\": \"slab_ring_cylinder\", \"mode\": \"emulated chain on one GPU\", \"slabs\": %d, \"rows_per_slab\": %d, "
+              "\"cols\": %d, \"global_rows\": %d, \"markers\": %d, \"band_rows\": [%d, %d], \"steps_per_block\": %d, \"steps\": %d, \"per_slab\": [",
+              N, R, C, Rg, (int)mx.size(), b0, b1, D, steps);
+  for (int r = 0; r < N; ++r)
+    std::printf("%s{\"slab\": %d, \"owner\": %d, \"straddle_prev\": %d, \"straddle_next\": %d, \"ms_per_block\": %.4f, \"mlups\": %.1f}",
+                r ? ", " : "", r, S[r].owner, S[r].sp, S[r].sn, S[r].ms / nb, (double)R * C * D / (S[r].ms / nb) / 1e3);
+  std::printf("], \"Fs\": [%.17g, %.17g]%s}\n", Fs[0], Fs[1],
+              a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
+  std::fflush(stdout);
+  for (auto& sb : S) {
+    lbm_slab_ibm_destroy(sb.sl);
+    for (double* p : {sb.lat[0], sb.lat[1], sb.buf[0][0], sb.buf[0][1], sb.buf[1][0], sb.buf[1][1]}) lbm_free(p);
+  }
   return bad ? 3 : 0;
 }
 
@@ -205,12 +342,16 @@ int main(int argc, char** argv) {
   a.cols = std::atoi(arg_value(argc, argv, "--cols", "4096").c_str());
   a.steps = std::atoi(arg_value(argc, argv, "--steps", "50").c_str());
   a.warmup = std::atoi(arg_value(argc, argv, "--warmup", "5").c_str());
-  a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "8").c_str());
+  a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "32").c_str());
+  a.depth = std::atoi(arg_value(argc, argv, "--depth", "5").c_str());
+  a.centre_row = std::atoi(arg_value(argc, argv, "--centre-row", "-1").c_str());
+  a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.diameter = std::atoi(arg_value(argc, argv, "--diameter", "300").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
   a.id_file = arg_value(argc, argv, "--id-file", "/tmp/lbm_ring_id." + std::to_string((long)getpid()));
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
   try {
+    if (a.emulate > 0) return run_emulated(a, a.emulate);
     if (spawn > 0) {
       cleanup_ring_files(a.id_file, spawn);  // a stale id file of a killed run must not be picked up
       const int rc = spawn_ranks(spawn, [&](int r) { return run_rank(a, r, spawn, r); });

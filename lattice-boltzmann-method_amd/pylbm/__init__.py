@@ -93,6 +93,7 @@ def load_library(path=LIB_PATH):
     lib.lbm_last_error_string.restype = ct.c_char_p
     lib.lbm_default_plane_pad.restype = ct.c_longlong
     lib.lbm_solver_block_launches.restype = ct.c_longlong
+    lib.lbm_slab_ibm_msg_doubles.restype = ct.c_longlong
     return lib
 
 
@@ -282,6 +283,46 @@ class Ibm:
     def close(self):
         if self.h:
             self.lib.ibm_destroy(self.h)
+            self.h = ct.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SlabIbm:
+    """Python face of lbm_slab_ibm: one BGK row slab of a domain with an immersed boundary, advanced in
+    blocks of `depth` steps (capi_slab_ibm.hip).  The transport between slabs is the caller's."""
+
+    def __init__(self, lib, geom, slab_row0, rows_global, bc_global, prm, depth, x, y, m_max=5,
+                 guo=(1.0 / 3.0, 1.0 / 9.0)):
+        self.lib, self.geom = lib, geom
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self.h = ct.c_void_p()
+        lib.slab_ibm_create(ct.byref(self.h), ct.byref(geom), int(slab_row0), int(rows_global), ct.byref(bc_global),
+                            ct.byref(prm), int(depth), _hptr(x), _hptr(y), len(x), int(m_max),
+                            ct.c_double(guo[0]), ct.c_double(guo[1]))
+        v = [ct.c_int() for _ in range(5)]
+        lib.slab_ibm_info(self.h, *[ct.byref(i) for i in v])
+        self.owner, self.straddle_prev, self.straddle_next, self.b0, self.b1 = (i.value for i in v)
+        self.msg_doubles = int(lib.raw.lbm_slab_ibm_msg_doubles(self.h))
+
+    def prime_counts(self, side):
+        a, b = ct.c_longlong(), ct.c_longlong()
+        self.lib.slab_ibm_prime_counts(self.h, int(side), ct.byref(a), ct.byref(b))
+        return a.value, b.value
+
+    def surface_force(self):
+        out = np.zeros(2)
+        self.lib.slab_ibm_surface_force(self.h, _hptr(out), None)
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.slab_ibm_destroy(self.h)
             self.h = ct.c_void_p()
 
     def __del__(self):

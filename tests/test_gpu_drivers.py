@@ -167,10 +167,11 @@ def test_slab_ring_rt_driver(tmp_path):
 
 
 def test_slab_ring_cylinder_driver(tmp_path):
-    """C++ host of config 5 over slabs (drivers/slab_ring_cylinder.cpp on lbm_ring_bgk_step_ibm): slab
-    geometry with a ghost row, moments written for the ROI rows only, forcing overlapped with the halo
-    stream.  --check: populations and surface force equal the single-block solver-context run bit for
-    bit.  (One rank: the chain has no neighbour; the exchange is covered by the self-ring tests.)"""
+    """C++ host of config 5 over slabs (drivers/slab_ring_cylinder.cpp on lbm_ring_ibm_start /
+    lbm_ring_bgk_block_ibm): 5-step blocks, the band around the ROI in a compact replica beside the far
+    rows.  --check: populations and surface force equal the single-block solver-context run bit for bit.
+    (One rank: the chain has no neighbour; the exchange is covered by the self-ring tests and by the
+    emulated chain below.)"""
     import json
     exe = os.path.join(BIN, "slab_ring_cylinder")
     assert os.path.exists(exe)
@@ -181,6 +182,22 @@ def test_slab_ring_cylinder_driver(tmp_path):
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["check"] == "bitwise equal to one block"
     assert line["markers"] == 94 and abs(line["Fs"][0]) > 0
+    assert line["this_rank"]["owner"] == 1 and line["steps_per_block"] == 5
+
+
+def test_slab_ring_cylinder_emulated_chain_with_the_cylinder_on_a_seam(tmp_path):
+    """the BASELINE layout in small: 4 slabs, the cylinder centred at rows / 4 = exactly the seam between
+    slabs 0 and 1 -- both co-own the band; every slab in turn on one GPU, messages by device copies;
+    == the single block bit for bit (populations of every slab, surface force of both co-owners)"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_cylinder")
+    r = subprocess.run([exe, "--emulate", "4", "--rows", "96", "--cols", "160", "--diameter", "30", "--steps", "15",
+                        "--warmup", "5", "--check", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block"
+    roles = [(s["owner"], s["straddle_prev"], s["straddle_next"]) for s in line["per_slab"]]
+    assert roles == [(1, 0, 1), (1, 1, 0), (0, 0, 0), (0, 0, 0)], roles
 
 
 def test_ulbm_poiseuille_driver_vs_oracle(tmp_path, oracle):

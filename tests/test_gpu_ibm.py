@@ -264,3 +264,124 @@ def test_cylinder_with_reassociated_delta_form(lib, oracle):
         lib.set_tuning(b"bgk_fast", -1)
     assert relerr(f, fo) < 1e-10, relerr(f, fo)
     assert np.allclose(Fs, Fso, rtol=1e-8, atol=1e-14)
+
+
+# ---- config 5 over slabs in blocks of D steps, the boundary anywhere -- also across a seam -------------
+def _slab_block_run(lib, oracle, X, Y, n_slabs, cx, radius, D, n_blocks, start_from_pre=False):
+    """the run through lbm_slab_ibm_* on n_slabs emulated slabs (one GPU, messages moved by device copies)
+    and the same run on ONE block through the solver context; returns (P_slabs, P_block, Fs_slabs, Fs_block,
+    slab objects' roles)"""
+    R = X // n_slabs
+    omega, u_in = 1.0 / 0.55, 0.05
+    x, y = circle(cx, Y / 2 + 0.21, radius)
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+    prm = pylbm.BgkParams(omega, 0, 1)
+    bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=pylbm.EDGE_SPECULAR,
+                  col_hi=pylbm.EDGE_SPECULAR, uw_r=u_in)
+    n = 1 + D * n_blocks
+    # one block through the solver context (collide-first + forced blocks, == single steps == oracle elsewhere)
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, prm, bc=bc)
+    ibw = pylbm.Ibm(lib, x, y, X, Y)
+    sv.attach_ibm(ibw)
+    sv.set_f(f0)
+    sv.step(n)
+    want, Fw = sv.get_f(), ibw.surface_force()
+    sv.close(); ibw.close()
+    # first iteration on the whole block: collide, forcing, source (cylinder_test.cpp:103-127)
+    d = dev()
+    flat = pylbm.Geom(X, Y, 0)
+    ib_flat = pylbm.Ibm(lib, x, y, X, Y)
+    f0d = upload_soa(lib, f0)
+    p0 = torch.empty((9, X, Y), dtype=torch.float64, device=d)
+    rho = torch.empty((X, Y), dtype=torch.float64, device=d)
+    u = torch.empty((2, X, Y), dtype=torch.float64, device=d)
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(flat), ct.byref(bc), ct.byref(prm), _ptr(rho), _ptr(u), None)
+    lib.ibm_force(ib_flat.h, _ptr(u), _ptr(rho), None, None)
+    lib.ibm_add_source(ib_flat.h, _ptr(p0), ct.byref(flat), _ptr(u), ct.c_double(omega), ct.c_double(1 / 3), ct.c_double(1 / 9), None)
+    torch.cuda.synchronize()
+    ib_flat.close()
+    geom = pylbm.Geom(R, Y, D)
+    slabs = [pylbm.SlabIbm(lib, geom, s * R, X, bc, prm, D, x, y) for s in range(n_slabs)]
+    lat = [[torch.zeros((9, R + 2 * D, Y), dtype=torch.float64, device=d) for _ in range(2)] for _ in range(n_slabs)]
+    for s in range(n_slabs):
+        lat[s][0][:, D:R + D] = p0[:, s * R:(s + 1) * R]
+    z = lambda k: torch.zeros(max(int(k), 1), dtype=torch.float64, device=d)
+
+    def exchange(pack, finish, counts):
+        """pack on every slab, move next->prev / prev->next, finish on every slab"""
+        bufs = []
+        for s, sl in enumerate(slabs):
+            c = counts(sl)
+            b = dict(sp=z(c[0][0]), rp=z(c[0][1]), sn=z(c[1][0]), rn=z(c[1][1]))
+            bufs.append(b)
+            pack(s, sl, b)
+        torch.cuda.synchronize()
+        for s in range(n_slabs - 1):
+            assert bufs[s]["sn"].numel() == bufs[s + 1]["rp"].numel() and bufs[s + 1]["sp"].numel() == bufs[s]["rn"].numel()
+            bufs[s + 1]["rp"].copy_(bufs[s]["sn"])
+            bufs[s]["rn"].copy_(bufs[s + 1]["sp"])
+        torch.cuda.synchronize()
+        for s, sl in enumerate(slabs):
+            finish(s, sl, bufs[s])
+        torch.cuda.synchronize()
+
+    cur = 0
+    if start_from_pre:   # the first iteration over the slabs themselves, from the PRE-collision state
+        pre = [torch.zeros((9, R + 2 * D, Y), dtype=torch.float64, device=d) for _ in range(n_slabs)]
+        for s in range(n_slabs):
+            pre[s][:, D:R + D] = f0d[:, s * R:(s + 1) * R]
+            lat[s][0].zero_()
+        exchange(lambda s, sl, b: lib.slab_ibm_prime_pack(sl.h, _ptr(pre[s]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+                 lambda s, sl, b: lib.slab_ibm_start_finish(sl.h, _ptr(lat[s][0]), _ptr(pre[s]), _ptr(b["rp"]), _ptr(b["rn"]), None),
+                 lambda sl: (sl.prime_counts(0), sl.prime_counts(1)))
+        for s in range(n_slabs):   # == the whole-block first iteration, ghost rows aside
+            assert torch.equal(lat[s][0][:, D:R + D], p0[:, s * R:(s + 1) * R]), s
+    else:
+        exchange(lambda s, sl, b: lib.slab_ibm_prime_pack(sl.h, _ptr(lat[s][cur]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+                 lambda s, sl, b: lib.slab_ibm_prime_finish(sl.h, _ptr(lat[s][cur]), _ptr(b["rp"]), _ptr(b["rn"]), None),
+                 lambda sl: (sl.prime_counts(0), sl.prime_counts(1)))
+    for _ in range(n_blocks):
+        m = lambda sl: ((sl.msg_doubles,) * 2, (sl.msg_doubles,) * 2)
+        exchange(lambda s, sl, b: lib.slab_ibm_block_compute(sl.h, _ptr(lat[s][cur ^ 1]), _ptr(lat[s][cur]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+                 lambda s, sl, b: lib.slab_ibm_block_finish(sl.h, _ptr(lat[s][cur ^ 1]), _ptr(b["rp"]), _ptr(b["rn"]), None), m)
+        cur ^= 1
+    P = torch.cat([lat[s][cur][:, D:R + D] for s in range(n_slabs)], dim=1).contiguous()
+    out = torch.empty_like(P)
+    lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc), None)
+    got = download_aos(lib, out)
+    owners = [s for s, sl in enumerate(slabs) if sl.owner]
+    Fs = [slabs[s].surface_force() for s in owners]
+    roles = [(sl.owner, sl.straddle_prev, sl.straddle_next) for sl in slabs]
+    for sl in slabs:
+        sl.close()
+    return got, want, Fs, Fw, roles
+
+
+@pytest.mark.parametrize("case", ["on_the_seam", "inside_slab0", "band_into_ghost_rows", "three_slabs_seam_1_2",
+                                  "off_centre_on_seam", "depth3_on_seam"])
+def test_cylinder_blocks_over_slabs_equal_single_block(lib, oracle, case):
+    """the cylinder centred ON a seam (the BASELINE geometry: centre at rows/4 of 8 slabs),
+    in blocks of D = 5 steps: both co-owners run the band chain, swap the band's outer rows, nothing else
+    changes -- populations and surface force equal the single block bit for bit.  Also the boundary wholly
+    inside one slab, the band reaching into (but its valid rows not across) the ghost rows, three slabs
+    with a non-owner, an off-centre straddle and D = 3."""
+    X, Y, n_slabs, radius, D, nb = 256, 96, 2, 10.0, 5, 3
+    if case == "on_the_seam":
+        cx, want_roles = 128.3, [(1, 0, 1), (1, 1, 0)]
+    elif case == "inside_slab0":
+        cx, want_roles = 60.4, [(1, 0, 0), (0, 0, 0)]
+    elif case == "band_into_ghost_rows":
+        cx, want_roles = 107.4, [(1, 0, 0), (0, 0, 0)]
+    elif case == "three_slabs_seam_1_2":
+        X, n_slabs, cx, want_roles = 384, 3, 255.6, [(0, 0, 0), (1, 0, 1), (1, 1, 0)]
+    elif case == "off_centre_on_seam":
+        cx, want_roles = 137.8, [(1, 0, 1), (1, 1, 0)]
+    else:
+        cx, D, nb, want_roles = 128.3, 3, 4, [(1, 0, 1), (1, 1, 0)]
+    got, want, Fs, Fw, roles = _slab_block_run(lib, oracle, X, Y, n_slabs, cx, radius, D, nb,
+                                               start_from_pre=case in ("on_the_seam", "three_slabs_seam_1_2", "band_into_ghost_rows"))
+    assert [tuple(int(v) for v in r) for r in roles] == want_roles, roles
+    assert bits_equal(got, want), (case, ulp_diff(got, want))
+    for F in Fs:                      # every co-owner holds the same forcing, bit for bit
+        assert np.array_equal(F, Fw), (case, F, Fw)
