@@ -107,13 +107,50 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     return LBM_OK;
   }
   const int inner = (rc.ir1 - rc.ir0) * (rc.ic1 - rc.ic0), frame = tiles - inner;
+  // the frame (3-4 % of the tiles, latency-bound: 63 us on its own) goes FIRST and on the helper stream, so
+  // that it runs beside the inner launch instead of behind it (fork / join through two events, launch.hpp)
+  SwSideStream* sd = frame > 0 && tuning("cg_frame_beside", 1) ? sw_side_stream() : nullptr;
+  hipStream_t fs = st;
+  if (sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->st, sd->fork, 0) == hipSuccess) fs = sd->st;
+  if (frame > 0) {
+    if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 2>), dim3(frame), dim3(TR * TC), 0, fs, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
+    else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 2>), dim3(frame), dim3(TR * TC), 0, fs, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
+    LBM_CHECK_LAUNCH();
+  }
+  if (const int sw = tuning("cg_strip2", 0)) {  // the inner rectangle through a register-ring strip kernel
+    // 1, 2, 4: k_cg_strip2 (one wave per SIMD) with that many waves per workgroup; 11, 12: k_cg_strip3 (colour sums
+    // of the ring rows in LDS, two waves per SIMD) with 1 / 2 waves per workgroup
+    const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
+    const int strips = (cb - ca + CG_SW2 - 1) / CG_SW2;
+    const void* kfn = sw == 2 ? (psi ? (const void*)k_cg_strip2<2, true> : (const void*)k_cg_strip2<2, false>)
+                    : sw == 1 ? (psi ? (const void*)k_cg_strip2<1, true> : (const void*)k_cg_strip2<1, false>)
+                    : sw == 11 ? (psi ? (const void*)k_cg_strip3<1, true> : (const void*)k_cg_strip3<1, false>)
+                    : sw == 12 ? (psi ? (const void*)k_cg_strip3<2, true> : (const void*)k_cg_strip3<2, false>)
+                               : (psi ? (const void*)k_cg_strip2<4, true> : (const void*)k_cg_strip2<4, false>);
+    const int wv = sw == 2 || sw == 12 ? 2 : (sw == 1 || sw == 11 ? 1 : 4);
+    // rows per wave: at 16.8 M nodes the launch is only 1-3 rounds of resident waves deep -- a chunk height
+    // that leaves the last round nearly empty costs up to a whole round; fit it to the resident wave slots
+    int rpc = tuning("cg_rows2", 0);
+    if (rpc <= 0) {
+      const long slots = sw_wave_slots(kfn, 64 * wv);
+      rpc = slots > 0 ? sw_pick_rows(rb - ra, strips, 3, slots) : 64;
+    }
+    if (rpc > rb - ra) rpc = rb - ra;
+    const int chunks = (rb - ra + rpc - 1) / rpc, n_waves = strips * chunks;
+#define LBM_CG_S2(KERNEL, WV)                                                                                      \
+    if (psi) LBM_KLAUNCH((KERNEL<WV, true>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves); \
+    else LBM_KLAUNCH((KERNEL<WV, false>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves);
+    if (sw == 2) { LBM_CG_S2(k_cg_strip2, 2) } else if (sw == 1) { LBM_CG_S2(k_cg_strip2, 1) }
+    else if (sw == 11) { LBM_CG_S2(k_cg_strip3, 1) } else if (sw == 12) { LBM_CG_S2(k_cg_strip3, 2) }
+    else { LBM_CG_S2(k_cg_strip2, 4) }
+#undef LBM_CG_S2
+  } else
   if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
   else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
   LBM_CHECK_LAUNCH();
-  if (frame > 0) {
-    if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 2>), dim3(frame), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
-    else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 2>), dim3(frame), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
-    LBM_CHECK_LAUNCH();
+  if (fs != st) {
+    LBM_CHECK_HIP(hipEventRecord(sd->join, fs));
+    LBM_CHECK_HIP(hipStreamWaitEvent(st, sd->join, 0));
   }
   return LBM_OK;
 }

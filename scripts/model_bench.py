@@ -101,6 +101,15 @@ def bench_cg(R, C, n=20):
             report("colour-gradient MRT (one launch per step, column strips, %s wave(s)/block, %s rows/chunk)" % (strip, rows), R, C, dt, 288)
     lib.set_tuning(b"cg_rows", -1)
     lib.set_tuning(b"cg_strip", 0)
+    for s2 in [x for x in os.environ.get("LBM_CG_STRIP2", "").split(",") if x]:
+        for rows in os.environ.get("LBM_CG_ROWS2", "64").split(","):
+            lib.set_tuning(b"cg_fused", 1)
+            lib.set_tuning(b"cg_strip2", int(s2))
+            lib.set_tuning(b"cg_rows2", int(rows))
+            dt = timed(lambda k: sv.step(k), n, warm=3)
+            report("colour-gradient MRT (inner rectangle: register-ring strips, %s wave(s)/block, %s rows/chunk; frame: tiles)" % (s2, rows), R, C, dt, 288)
+    lib.set_tuning(b"cg_strip2", 0)
+    lib.set_tuning(b"cg_rows2", -1)
     tiles = os.environ.get("LBM_CG_TILES", "4").split(",")
     for tile in tiles:
         for xcd in os.environ.get("LBM_CG_XCD", "2").split(","):
@@ -115,6 +124,7 @@ def bench_cg(R, C, n=20):
     report("colour-gradient MRT (two-pass, reference operation order)", R, C, dt, 496)
     lib.set_tuning(b"cg_fused", -1)
     lib.set_tuning(b"cg_strip", -1)
+    lib.set_tuning(b"cg_strip2", -1)
     lib.set_tuning(b"cg_tile", -1)
     sv.close()
 

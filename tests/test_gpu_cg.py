@@ -305,8 +305,12 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
     try:
         # (0, 64): tile kernel split into inner tiles (plain gathers) + frame; (0, 0): every tile through
         # the general boundary gather
-        for strip, rows in ((0, 64), (0, 0), (1, 64), (4, 24), (2, 7)):
-            lib.set_tuning(b"cg_strip", strip)
+        # strip >= 10: the inner rectangle through the register-ring strip kernel (cg_strip2 = strip - 10 waves
+        # per workgroup, cg_rows2 rows per chunk), the frame through the tile kernel
+        for strip, rows in ((0, 64), (0, 0), (1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33), (21, 40), (22, 9)):
+            lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
+            lib.set_tuning(b"cg_strip2", strip - 10 if strip >= 10 else 0)
+            lib.set_tuning(b"cg_rows2", rows if rows else 64)
             lib.set_tuning(b"cg_rows", rows if rows else 64)
             lib.set_tuning(b"cg_split", 1 if rows else 0)
             a, b = [x.clone() for x in p], [torch.empty_like(p[0]) for _ in range(2)]
@@ -318,6 +322,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
             res[(strip, rows)] = a
     finally:
         lib.set_tuning(b"cg_strip", -1)
+        lib.set_tuning(b"cg_strip2", -1)
+        lib.set_tuning(b"cg_rows2", -1)
         lib.set_tuning(b"cg_rows", -1)
         lib.set_tuning(b"cg_split", -1)
     ref = res[(0, 0)]
