@@ -169,6 +169,43 @@ class Box:
             self.ring = None
 
 
+def pmc_traffic(argv_tail, kernel_tag="k_stream_collide_sw", timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under
+    `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE each in its own pass, as MI355X_MICROARCH.md prescribes;
+    FETCH_SIZE x 2 = the gfx950 correction for wide coalesced reads, calibrated in profiles/).  Returns
+    (fetch_bytes, write_bytes, note) or (None, None, reason).  The children only launch the kernel a few
+    times (--pmc-child); nothing here is timed."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None, "rocprofv3 not found"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lbm_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child"] + argv_tail
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=timeout_s)
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        vals.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or len(vals) < 3:
+                return None, None, f"{counter} pass failed (rc {r.returncode}, {len(vals)} samples)"
+            out[counter] = statistics.median(vals[2:]) * 1024.0     # KiB; the first launches warm the caches
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+            return None, None, f"{counter} pass: {type(e).__name__}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return 2.0 * out["FETCH_SIZE"], out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE x 2: gfx950)"
+
+
 def timed_batches(box, steps, repeats, world, dev):
     """`repeats` batches of exactly `steps` steps, each bracketed by barrier + synchronize; returns
     per-repeat (wall seconds, device ms between HIP events on the launch stream), MAX over ranks."""
@@ -217,6 +254,9 @@ def main():
     ap.add_argument("--sw-rows", type=int, default=-1,
                     help="rows per wavefront chunk of the sliding-window kernel (-1: fitted by the launcher to the resident wave slots)")
     ap.add_argument("--edge-rows", type=int, default=32, help="rows at each slab end computed ahead of the halo exchange")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure HBM traffic with rocprofv3 --pmc child runs (N = 1); report the committed profile's figure")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--force-halo", action="store_true",
                     help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv every launch)")
     a = ap.parse_args()
@@ -248,6 +288,13 @@ def main():
     f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
     box.load(f0)
     del f0
+
+    if a.pmc_child:   # under rocprofv3 --pmc: a few launches of the dominant kernel, nothing else
+        for _ in range(8):
+            box.launch(D)
+        torch.cuda.synchronize()
+        box.close()
+        return
 
     # -- warm-up: --warmup steps, then keep launching until MIN_WARM_S of GPU work has run ------
     box.advance(a.warmup)
@@ -325,6 +372,15 @@ def main():
         # be read from inside this process: the figure is the committed profile of this very kernel
         # on this very lattice, else null
         traffic, traffic_src, valu = None, None, None
+        live = None
+        if world == 1 and not box.ring and D >= 2 and not a.no_pmc:
+            tail = ["--rows", str(R), "--cols", str(C), "--omega", str(a.omega), "--xn", str(a.xn), "--sw-rows", str(a.sw_rows)]
+            for kv in a.tune:
+                tail += ["--tune", kv]
+            if a.plane_pad is not None:
+                tail += ["--plane-pad", str(a.plane_pad)]
+            fb, wb_, note = pmc_traffic(tail)
+            live = {"fetch_bytes": fb, "write_bytes": wb_, "note": note}
         try:
             tj = json.load(open(TRAFFIC_FILE))
             ent = tj.get(kernel)
@@ -334,6 +390,9 @@ def main():
                 valu = ent.get("valu_issue_frac")
         except (OSError, ValueError, KeyError):
             pass
+        if live and live["fetch_bytes"]:
+            traffic = live["fetch_bytes"] + live["write_bytes"]
+            traffic_src = live["note"]
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": kernel,
                 "kernel_ms": round(kern_ms, 4) if kern_ms else None, "steps_per_launch": D,
@@ -354,6 +413,10 @@ def main():
                 roof["achieved"], roof["frac"] = round(alg, 1), round(alg / HBM_PEAK_GBS, 4)
         if valu is not None:
             roof["valu_issue_frac"] = valu
+            roof["valu_issue_frac_source"] = "committed SQ pass (profiles/), not this run"
+        if live:
+            roof["pmc"] = live
+            roof["minimum_bytes_per_launch"] = R * C * BYTES_PER_LUP     # one read + one write of the lattice
         out = {
             "metric": "MLUPS (million lattice updates/sec), D2Q9 BGK periodic box, f64",
             "value": round(lups / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": a.steps,
