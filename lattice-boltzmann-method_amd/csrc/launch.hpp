@@ -358,6 +358,35 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
     LBM_CHECK_LAUNCH();
     return LBM_OK;
   }
+  bool launched = false;
+  if constexpr (std::is_same<Model, BgkFastModel>::value || std::is_same<Model, BgkModelT<0, 0>>::value) {
+    // paired strips (d2q9.hpp k_stream_collide_swp): the 2 / 4 waves of a workgroup hand each other their edge columns
+    const int pw = tuning("sw_pair", 0);
+    if ((pw == 2 || pw == 4) && depth == 5 && nt && g.C >= 256) {
+      const int GW = swp_group_width(5, pw), groups = (g.C + GW - 1) / GW;
+      int rows = tuning("sw_rows", -1);
+      if (second_begin >= 0) rows = nrows;
+      else if (rows <= 0) {
+        const long slots = pw == 2 ? sw_wave_slots((const void*)k_stream_collide_swp<Model, 5, 2, true>, 128)
+                                   : sw_wave_slots((const void*)k_stream_collide_swp<Model, 5, 4, true>, 256);
+        rows = slots > 0 ? sw_pick_rows(nrows, groups * pw, 7, slots) : 64;  // 12 pipeline rows per chunk ~ depth 7
+      }
+      if (rows > nrows) rows = nrows;
+      const int chunks = second_begin >= 0 ? 2 : (nrows + rows - 1) / rows, total = groups * chunks;
+      if (pw == 2) LBM_KLAUNCH((k_stream_collide_swp<Model, 5, 2, true>), dim3(total), dim3(128), 0, st, pn, po, g, m, row_begin, row_end_k, rows, groups, total, chunk_stride);
+      else LBM_KLAUNCH((k_stream_collide_swp<Model, 5, 4, true>), dim3(total), dim3(256), 0, st, pn, po, g, m, row_begin, row_end_k, rows, groups, total, chunk_stride);
+      launched = true;
+    }
+  }
+  if constexpr (std::is_same<Model, BgkFastModel>::value) {
+    if (!launched && tuning("sw_pf2", 0) && depth == 5 && waves == 2 && nt) {  // level-1 rows prefetched two iterations ahead
+      plan((const void*)k_stream_collide_sw<Model, 5, 2, true, false, true>, 128);
+      LBM_KLAUNCH((k_stream_collide_sw<Model, 5, 2, true, false, true>), dim3((n_waves + 1) / 2), dim3(128), 0, st, pn, po, g, m,
+                  row_begin, row_end_k, rpc, strips, n_waves, tuning("sw_xcd", 0), Bc{}, 0, chunk_stride);
+      launched = true;
+    }
+  }
+  if (!launched) {
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
     plan((const void*)k_stream_collide_sw<Model, DV, WV, true>, 64 * WV);                         \
@@ -369,6 +398,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   LBM_SW(2, 1) LBM_SW(3, 1) LBM_SW(4, 1) LBM_SW(2, 2) LBM_SW(3, 2) LBM_SW(4, 2) LBM_SW(5, 2) LBM_SW(6, 2) {
     set_error("%s: no sliding-window instantiation for depth=%d sw_waves=%d", fn, depth, waves);
     return LBM_ERR_INVALID;
+  }
   }
 #undef LBM_SW
   LBM_CHECK_LAUNCH();

@@ -836,3 +836,35 @@ def test_ghost_rows_reject_periodic_row_edges(lib):
     bc.row_hi = pylbm.EDGE_HALO
     lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(g), ct.byref(bc), ct.byref(prm), 0, R, None, None, None)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("R,C", [(64, 256), (96, 300), (130, 512), (75, 1000)])
+def test_paired_strip_and_deep_prefetch_windows_bit_identical(lib, oracle, R, C):
+    """The two further forms of the 5-step window: "sw_pair" = 2 / 4 (the waves of a workgroup own adjacent
+    windows and hand each other the edge columns of every level through LDS; levels lag by two rows, one
+    barrier per iteration) and "sw_pf2" = 1 (level-1 rows prefetched two iterations ahead).  Same arithmetic
+    per node: 2 launches == 10 single steps == oracle bit for bit; partial last group, chunks that do not divide
+    R, column counts that wrap inside a group."""
+    f0 = random_state(oracle, R, C, seed=7 * R + C)
+    prm = pylbm.BgkParams(1.5, 0)
+    g = pylbm.Geom(R, C, 0)
+    f0d = upload_soa(lib, f0)
+    p0 = torch.empty((9, R, C), dtype=torch.float64, device=dev())
+    lib.bgk_collide(_ptr(p0), _ptr(f0d), ct.byref(g), None, ct.byref(prm), None, None, None)
+    out = torch.empty_like(p0)
+    want, _, _ = oracle.bgk_periodic_steps(f0, 1.5, 11)
+    try:
+        for pair, pf2, rows in [(2, 0, 32), (2, 0, -1), (4, 0, 17), (4, 0, -1), (0, 1, 32), (0, 1, -1), (2, 0, 256)]:
+            lib.set_tuning(b"sw_pair", pair)
+            lib.set_tuning(b"sw_pf2", pf2)
+            lib.set_tuning(b"sw_rows", rows)
+            a, b = p0.clone(), torch.zeros_like(p0)
+            for _ in range(2):
+                lib.bgk_stream_collide_xn(_ptr(b), _ptr(a), ct.byref(g), None, ct.byref(prm), 5, 0, R, None)
+                a, b = b, a
+            lib.stream(_ptr(out), _ptr(a), ct.byref(g), None, None)
+            got = download_aos(lib, out)
+            assert bits_equal(got, want), (pair, pf2, rows, ulp_diff(got, want))
+    finally:
+        for k in (b"sw_pair", b"sw_pf2", b"sw_rows"):
+            lib.set_tuning(k, -1)
