@@ -140,10 +140,18 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
 #define LBM_CG_S2(KERNEL, WV)                                                                                      \
     if (psi) LBM_KLAUNCH((KERNEL<WV, true>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves); \
     else LBM_KLAUNCH((KERNEL<WV, false>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves);
+    const int xo = tuning("cg_strip_xcd", 0);  // strip3: XCD k takes the k-th contiguous eighth of the strip sequence (measured: no effect)
+#define LBM_CG_S3(WV)                                                                                              \
+    {                                                                                                              \
+      const int nblk = (n_waves + WV - 1) / WV, grid3 = xo ? ((nblk + 7) / 8) * 8 : nblk;                          \
+      if (psi) LBM_KLAUNCH((k_cg_strip3<WV, true>), dim3(grid3), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves, xo); \
+      else LBM_KLAUNCH((k_cg_strip3<WV, false>), dim3(grid3), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves, xo); \
+    }
     if (sw == 2) { LBM_CG_S2(k_cg_strip2, 2) } else if (sw == 1) { LBM_CG_S2(k_cg_strip2, 1) }
-    else if (sw == 11) { LBM_CG_S2(k_cg_strip3, 1) } else if (sw == 12) { LBM_CG_S2(k_cg_strip3, 2) }
+    else if (sw == 11) LBM_CG_S3(1) else if (sw == 12) LBM_CG_S3(2)
     else { LBM_CG_S2(k_cg_strip2, 4) }
 #undef LBM_CG_S2
+#undef LBM_CG_S3
   } else
   if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
   else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);

@@ -746,11 +746,16 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_cg_strip3(
     const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
     double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
     double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
-    int rows_per_chunk, int strips, int n_waves) {
+    int rows_per_chunk, int strips, int n_waves, int xcd_order) {
   __shared__ double ring[WAVES][3][5][68];  // [wave][field][slot][2 pad + lane + 2 pad]
   __shared__ double ftr[WAVES][3][Q][64];   // [wave][ring row][population][lane]
   const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * WAVES + wib;
+  // workgroups are dealt round-robin over the 8 XCDs: with xcd_order, XCD k takes the k-th contiguous eighth of
+  // the (chunk-major, strip-minor) sequence, so that neighbouring strips -- which share the 128-byte lines at
+  // their window edges -- run back to back on one L2 instead of on eight different ones
+  int blk = blockIdx.x;
+  if (xcd_order) blk = (blk % 8) * ((int)gridDim.x / 8) + blk / 8;  // the launch pads the grid to a multiple of 8
+  const int wave = blk * WAVES + wib;
   if (wave >= n_waves) return;
   const int strip = wave % strips, chunk = wave / strips;
   const int R0 = row_begin + chunk * rows_per_chunk;

@@ -106,8 +106,11 @@ def bench_cg(R, C, n=20):
             lib.set_tuning(b"cg_fused", 1)
             lib.set_tuning(b"cg_strip2", int(s2))
             lib.set_tuning(b"cg_rows2", int(rows))
-            dt = timed(lambda k: sv.step(k), n, warm=3)
-            report("colour-gradient MRT (inner rectangle: register-ring strips, %s wave(s)/block, %s rows/chunk; frame: tiles)" % (s2, rows), R, C, dt, 288)
+            for xo in os.environ.get("LBM_CG_STRIP_XCD", "1").split(","):
+                lib.set_tuning(b"cg_strip_xcd", int(xo))
+                dt = timed(lambda k: sv.step(k), n, warm=3)
+                report("colour-gradient MRT (inner rectangle: register-ring strips, %s wave(s)/block, %s rows/chunk, xcd order %s; frame: tiles)" % (s2, rows, xo), R, C, dt, 288)
+            lib.set_tuning(b"cg_strip_xcd", -1)
     lib.set_tuning(b"cg_strip2", 0)
     lib.set_tuning(b"cg_rows2", -1)
     tiles = os.environ.get("LBM_CG_TILES", "4").split(",")
