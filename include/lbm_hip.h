@@ -480,6 +480,28 @@ int lbm_ring_ibm_start(lbm_ring* rg, lbm_slab_ibm* sl, double* post, double* pre
 int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const double* src, int edge_rows,
                            lbm_stream_t main);
 
+/* ---- pressure-periodic rows over slabs (horizontal_poiseuille_test.cpp:25-45 over the block binding of
+ * decompose_domain.cpp:50-73,181-187), blocks of `depth` steps.  The ring is PERIODIC: the virtual rows 0 / Rg-1 sit on
+ * its two end slabs, which replicate the small seam lattice of lbm_solver_step's pressure blocks and swap, per block, the
+ * D rows at distance [D, 2D) from the seam in place of that seam's halo (same size).  Transport-free: *_pack / *_compute
+ * fill two send buffers, *_finish consume two receive buffers (side 0 = previous slab, 1 = next).  BGK; bc_global: the
+ * domain's edges with pressure_rows = 1, periodic rows, periodic / wall columns.  Bitwise equal to the single block. */
+typedef struct lbm_slab_pressure lbm_slab_pressure;
+int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
+                             const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth);
+int lbm_slab_pressure_destroy(lbm_slab_pressure* sl);
+long long lbm_slab_pressure_msg_doubles(const lbm_slab_pressure* sl, int side, int start /* 1: the start-up exchange */);
+/* start-up from the driver's pre-collision state: exchange, then first iteration into `post` */
+int lbm_slab_pressure_start_pack(lbm_slab_pressure* sl, const double* pre, double* send_prev, double* send_next, lbm_stream_t s);
+int lbm_slab_pressure_start_finish(lbm_slab_pressure* sl, double* post, double* pre, const double* recv_prev,
+                                   const double* recv_next, lbm_stream_t s);
+int lbm_slab_pressure_block_compute(lbm_slab_pressure* sl, double* dst, const double* src, double* send_prev,
+                                    double* send_next, lbm_stream_t s);
+int lbm_slab_pressure_block_finish(lbm_slab_pressure* sl, double* dst, const double* recv_prev, const double* recv_next, lbm_stream_t s);
+/* the same over the slab ring (created periodic): start-up, then one block per call (exchange behind the compute) */
+int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, lbm_stream_t main);
+int lbm_ring_bgk_block_pressure(lbm_ring* rg, lbm_slab_pressure* sl, double* dst, const double* src, lbm_stream_t main);
+
 /* ---- population links between lattices on one GPU (multi-block topologies) -----------------------
  * The reference glues blocks by slice assignments after advect (test/decompose_domain.cpp:181-187;
  * test/decompose_domain_loop.cpp:235-261, plus its slice-assignment walls :173-231): here a table of

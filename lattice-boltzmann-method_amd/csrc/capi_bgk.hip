@@ -192,3 +192,11 @@ int lbm::bgk_stream_collide_xn_ref(double* p_new, const double* p_old, const lbm
   return bgk_xn("bgk_stream_collide_xn_ref", p_new, p_old, g, bc, prm, n_steps, row_begin, row_end, -1, (lbm_stream_t)st, false);
 }
 
+// internal: lbm_bgk_collide pinned to the reference operation order, no pressure rows (slabs of a lattice with
+// pressure-periodic rows collide their rows -- ghost rows included -- this way; the virtual rows come from the seam lattice)
+int lbm::bgk_collide_ref(double* p, const double* f, const lbm_geom* g, const lbm_bgk_params* prm, hipStream_t st) {
+  int rc = check_bgk("bgk_collide_ref", prm);
+  if (rc) return rc;
+  const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
+  return launch_collide_only("bgk_collide_ref", p, f, g, nullptr, m, nullptr, nullptr, st);
+}

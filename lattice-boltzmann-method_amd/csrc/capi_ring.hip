@@ -540,6 +540,46 @@ int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const do
   return lbm_slab_ibm_block_finish(sl, dst, rg->recv_prev, rg->recv_next, main_s);
 }
 
+// ---- pressure-periodic rows over the (periodic) ring: capi_slab_pressure.hip holds the engine ---------------------
+int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && sl && post && pre, "lbm_ring_pressure_start: NULL argument");
+  LBM_REQUIRE(rg->prev >= 0 && rg->next >= 0 && rg->nranks >= 2, "lbm_ring_pressure_start: needs a periodic ring of at least 2 slabs");
+  const size_t n_prev = (size_t)lbm_slab_pressure_msg_doubles(sl, 0, 1), n_next = (size_t)lbm_slab_pressure_msg_doubles(sl, 1, 1);
+  // (the partner of a seam sends what this side receives: the start-up messages across the pressure seam are both 2 D rows)
+  double* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  const size_t cnt[4] = {n_prev, n_prev, n_next, n_next};  // send_prev, recv_prev, send_next, recv_next
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipMalloc(&buf[k], cnt[k] * sizeof(double));
+  int rc = LBM_OK;
+  if (e != hipSuccess) {
+    set_error("lbm_ring_pressure_start: %s", hipGetErrorString(e));
+    rc = LBM_ERR_HIP;
+  }
+  hipStream_t main = as_stream(main_s);
+  if (!rc) rc = lbm_slab_pressure_start_pack(sl, pre, buf[0], buf[2], main_s);
+  if (!rc) rc = ring_sendrecv(rg, buf[0], n_prev, buf[1], n_prev, buf[2], n_next, buf[3], n_next, main);
+  if (!rc) rc = lbm_slab_pressure_start_finish(sl, post, pre, buf[1], buf[3], main_s);
+  if (!rc && hipStreamSynchronize(main) != hipSuccess) {
+    set_error("lbm_ring_pressure_start: stream synchronisation failed");
+    rc = LBM_ERR_HIP;
+  }
+  for (double* b : buf)
+    if (b) (void)hipFree(b);
+  return rc;
+}
+
+int lbm_ring_bgk_block_pressure(lbm_ring* rg, lbm_slab_pressure* sl, double* dst, const double* src, lbm_stream_t main_s) {
+  LBM_REQUIRE(rg && sl && dst && src, "lbm_ring_bgk_block_pressure: NULL argument");
+  LBM_REQUIRE(rg->prev >= 0 && rg->next >= 0, "lbm_ring_bgk_block_pressure: needs a periodic ring");
+  hipStream_t main = as_stream(main_s);
+  int rc = lbm_slab_pressure_block_compute(sl, dst, src, rg->send_prev, rg->send_next, main_s);
+  if (rc) return rc;
+  const size_t msg = (size_t)lbm_slab_pressure_msg_doubles(sl, 0, 0);
+  rc = ring_sendrecv(rg, rg->send_prev, msg, rg->recv_prev, msg, rg->send_next, msg, rg->recv_next, msg, main);
+  if (rc) return rc;
+  return lbm_slab_pressure_block_finish(sl, dst, rg->recv_prev, rg->recv_next, main_s);
+}
+
 // make `main` wait for an exchange enqueued with lbm_ring_exchange (initial ghost fill)
 int lbm_ring_join(lbm_ring* rg, lbm_stream_t main_s) {
   LBM_REQUIRE(rg, "lbm_ring_join: NULL ring");

@@ -22,6 +22,7 @@ int kbc_stream_collide_x2_ref(double* p_new, const double* p_old, const lbm_geom
 // capi_bgk.hip: lbm_bgk_stream_collide_xn pinned to the reference operation order
 int bgk_stream_collide_xn_ref(double* p_new, const double* p_old, const lbm_geom* g, const lbm_bc* bc,
                               const lbm_bgk_params* prm, int n_steps, int row_begin, int row_end, hipStream_t st);
+int bgk_collide_ref(double* p, const double* f, const lbm_geom* g, const lbm_bgk_params* prm, hipStream_t st);
 // NumPy .npy (v1.0, little-endian f64, C order) writer shared by the snapshot objects
 int write_npy(const char* path, const double* data, const std::vector<long>& shape);
 

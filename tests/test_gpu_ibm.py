@@ -385,3 +385,67 @@ def test_cylinder_blocks_over_slabs_equal_single_block(lib, oracle, case):
     assert bits_equal(got, want), (case, ulp_diff(got, want))
     for F in Fs:                      # every co-owner holds the same forcing, bit for bit
         assert np.array_equal(F, Fw), (case, F, Fw)
+
+
+def test_ring_ibm_block_wrappers_on_a_self_ring(lib, oracle):
+    """lbm_ring_ibm_start / lbm_ring_bgk_block_ibm (RCCL transport of the slab blocks) on hardware: one rank whose
+    two neighbours are itself (periodic self ring), playing the MIDDLE slab of a 3-slab domain that owns the
+    cylinder.  The messages it receives are its own -- physically meaningless, but the same bytes a plain device
+    copy of its send buffers delivers: the RCCL run must equal that emulation bit for bit (message sizes, order of
+    the sends / receives, stream ordering of compute -> exchange -> finish)."""
+    X, Y, R, D = 384, 96, 128, 5
+    omega, u_in = 1.0 / 0.55, 0.05
+    x, y = circle(R + 64.3, Y / 2 + 0.21, 10.0)
+    prm = pylbm.BgkParams(omega, 0, 1)
+    bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=pylbm.EDGE_SPECULAR,
+                  col_hi=pylbm.EDGE_SPECULAR, uw_r=u_in)
+    u0 = np.zeros((R, Y, 2)); u0[..., 0] = u_in
+    f0 = upload_soa(lib, oracle.incomp_equilibrium(u0, np.ones((R, Y))))
+    d = dev()
+    geom = pylbm.Geom(R, Y, D)
+    n_msg = 9 * D * Y
+
+    def fresh():
+        sl = pylbm.SlabIbm(lib, geom, R, X, bc, prm, D, x, y)
+        assert (sl.owner, sl.straddle_prev, sl.straddle_next) == (1, 0, 0)
+        pre = torch.zeros((9, R + 2 * D, Y), dtype=torch.float64, device=d)
+        pre[:, D:R + D] = f0
+        lat = [torch.zeros((9, R + 2 * D, Y), dtype=torch.float64, device=d) for _ in range(2)]
+        return sl, pre, lat
+
+    # emulation: what a self ring delivers is this slab's own send buffers
+    sl, pre, lat = fresh()
+    sp, sn = (torch.zeros(n_msg, dtype=torch.float64, device=d) for _ in range(2))
+    lib.slab_ibm_prime_pack(sl.h, _ptr(pre), _ptr(sp), _ptr(sn), None)
+    torch.cuda.synchronize()
+    rp, rn = sn.clone(), sp.clone()       # from prev (= self): its send_next; from next: its send_prev
+    lib.slab_ibm_start_finish(sl.h, _ptr(lat[0]), _ptr(pre), _ptr(rp), _ptr(rn), None)
+    cur = 0
+    for _ in range(3):
+        lib.slab_ibm_block_compute(sl.h, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), _ptr(sp), _ptr(sn), None)
+        torch.cuda.synchronize()
+        rp, rn = sn.clone(), sp.clone()
+        lib.slab_ibm_block_finish(sl.h, _ptr(lat[cur ^ 1]), _ptr(rp), _ptr(rn), None)
+        cur ^= 1
+    torch.cuda.synchronize()
+    want, Fw = lat[cur].clone(), sl.surface_force()
+    sl.close()
+    assert bool(torch.isfinite(want).all())
+    # the same through RCCL
+    sl, pre, lat = fresh()
+    ident = (ct.c_ubyte * 128)()
+    lib.ring_unique_id(ident)
+    ring = ct.c_void_p()
+    lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(geom), 1)
+    try:
+        lib.ring_ibm_start(ring, sl.h, _ptr(lat[0]), _ptr(pre), None)
+        cur = 0
+        for _ in range(3):
+            lib.ring_bgk_block_ibm(ring, sl.h, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), 16, None)
+            cur ^= 1
+        torch.cuda.synchronize()
+        assert torch.equal(lat[cur], want)
+        assert np.array_equal(sl.surface_force(), Fw)
+    finally:
+        lib.ring_destroy(ring)
+        sl.close()

@@ -108,3 +108,81 @@ def test_kbc_pressure_blocks_equal_single_steps(lib, H, W):
     assert bits_equal(got, want), (H, W, ulp_diff(got, want))
     got = run(lib, pylbm.MODEL_KBC, H, W, pylbm.KbcParams(s2), bc, f0, 12, -1, mom)
     assert bits_equal(got, want), (H, W, "default", ulp_diff(got, want))
+
+
+# ---- pressure-periodic rows over slabs (second half) -----------------------------------------
+@pytest.mark.parametrize("case,n_slabs,D", [("poiseuille_bb", 2, 5), ("poiseuille_bb", 3, 5), ("specular", 2, 3),
+                                            ("gravity", 3, 4), ("periodic_cols", 4, 2)])
+def test_pressure_rows_over_emulated_slabs_equal_single_block(lib, case, n_slabs, D):
+    """The channel presets over a PERIODIC ring of slabs, emulated on one GPU (messages moved by device copies):
+    the two end slabs replicate the small seam lattice and swap the rows at distance [D, 2D) from the virtual rows
+    per block; middle slabs are ordinary.  Start-up from the pre-collision state + 3 blocks == the single block
+    stepped one step per launch, bit for bit."""
+    import ctypes as ct
+    from gpu_util import dev, download_aos, upload_soa
+    from pylbm import _ptr
+    R, W = 64, 150
+    H = R * n_slabs
+    p = hpt_params(H, W, 0)
+    bc = pylbm.Bc(pressure_rows=1, rho_inlet=p.rho_inlet, rho_outlet=p.rho_outlet)
+    prm = pylbm.BgkParams(p.omega, 1)
+    if case == "poiseuille_bb":
+        bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+    elif case == "specular":
+        bc.col_lo = bc.col_hi = pylbm.EDGE_SPECULAR
+        prm = pylbm.BgkParams(p.omega, 0)
+    elif case == "gravity":
+        bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+        bc.rho_inlet = bc.rho_outlet = 1.0
+        prm = pylbm.BgkParams(p.omega, 1, force=(-0.0003, 0.0))
+    f0 = perturbed_rest(H, W, seed=H + W + D)
+    nb = 3
+    want = run(lib, pylbm.MODEL_BGK, H, W, prm, bc, f0, 1 + nb * D, 1)
+    d = dev()
+    geom = pylbm.Geom(R, W, D)
+    lib.raw.lbm_slab_pressure_msg_doubles.restype = ct.c_longlong
+    slabs = []
+    for s in range(n_slabs):
+        h = ct.c_void_p()
+        lib.slab_pressure_create(ct.byref(h), ct.byref(geom), s * R, H, ct.byref(bc), ct.byref(prm), D)
+        slabs.append(h)
+    f0d = upload_soa(lib, f0)
+    pre = [torch.zeros((9, R + 2 * D, W), dtype=torch.float64, device=d) for _ in range(n_slabs)]
+    lat = [[torch.zeros((9, R + 2 * D, W), dtype=torch.float64, device=d) for _ in range(2)] for _ in range(n_slabs)]
+    for s in range(n_slabs):
+        pre[s][:, D:R + D] = f0d[:, s * R:(s + 1) * R]
+
+    def exchange(pack, finish, start):
+        bufs = []
+        for s, h in enumerate(slabs):
+            n = [int(lib.raw.lbm_slab_pressure_msg_doubles(h, side, start)) for side in (0, 1)]
+            b = dict(sp=torch.zeros(n[0], dtype=torch.float64, device=d), rp=torch.zeros(n[0], dtype=torch.float64, device=d),
+                     sn=torch.zeros(n[1], dtype=torch.float64, device=d), rn=torch.zeros(n[1], dtype=torch.float64, device=d))
+            bufs.append(b)
+            pack(s, h, b)
+        torch.cuda.synchronize()
+        for s in range(n_slabs):   # periodic ring
+            nx = (s + 1) % n_slabs
+            assert bufs[s]["sn"].numel() == bufs[nx]["rp"].numel() and bufs[nx]["sp"].numel() == bufs[s]["rn"].numel()
+            bufs[nx]["rp"].copy_(bufs[s]["sn"])
+            bufs[s]["rn"].copy_(bufs[nx]["sp"])
+        torch.cuda.synchronize()
+        for s, h in enumerate(slabs):
+            finish(s, h, bufs[s])
+        torch.cuda.synchronize()
+
+    exchange(lambda s, h, b: lib.slab_pressure_start_pack(h, _ptr(pre[s]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+             lambda s, h, b: lib.slab_pressure_start_finish(h, _ptr(lat[s][0]), _ptr(pre[s]), _ptr(b["rp"]), _ptr(b["rn"]), None), 1)
+    cur = 0
+    for _ in range(nb):
+        exchange(lambda s, h, b: lib.slab_pressure_block_compute(h, _ptr(lat[s][cur ^ 1]), _ptr(lat[s][cur]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+                 lambda s, h, b: lib.slab_pressure_block_finish(h, _ptr(lat[s][cur ^ 1]), _ptr(b["rp"]), _ptr(b["rn"]), None), 0)
+        cur ^= 1
+    P = torch.cat([lat[s][cur][:, D:R + D] for s in range(n_slabs)], dim=1).contiguous()
+    out = torch.empty_like(P)
+    flat = pylbm.Geom(H, W, 0)
+    lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc), None)
+    got = download_aos(lib, out)
+    for h in slabs:
+        lib.slab_pressure_destroy(h)
+    assert bits_equal(got, want), (case, n_slabs, D, ulp_diff(got, want))
