@@ -184,7 +184,8 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   double* lats[2] = {lattice, lattice2};
   const int nl = lattice2 ? 2 : 1;
   const size_t count = msg * nl;
-  for (int k = 0; k < nl; ++k) {
+  const int skip = tuning("ring_debug_skip", 0);  // diagnosis only: 1 = no pack / unpack, 2 = no RCCL, 3 = neither (results wrong)
+  for (int k = 0; k < nl && !(skip & 1); ++k) {
     if (rg->next >= 0) {
       int rc = lbm_halo_pack(rg->send_next + k * msg, lats[k], &rg->g, G, 1, rg->edge);
       if (rc) return rc;
@@ -194,6 +195,7 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
       if (rc) return rc;
     }
   }
+  if (!(skip & 2)) {
   LBM_CHECK_NCCL(g_rccl.GroupStart());
   // sends (to next, to prev), receives (from prev, from next): with two ranks both neighbours
   // are the same peer and messages match in issue order
@@ -202,7 +204,8 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_prev, count, kNcclFloat64, rg->prev, rg->comm, rg->edge));
   if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_next, count, kNcclFloat64, rg->next, rg->comm, rg->edge));
   LBM_CHECK_NCCL(g_rccl.GroupEnd());
-  for (int k = 0; k < nl; ++k) {
+  }
+  for (int k = 0; k < nl && !(skip & 1); ++k) {
     if (rg->prev >= 0) {
       int rc = lbm_halo_unpack(lats[k], rg->recv_prev + k * msg, &rg->g, G, 0, rg->edge);
       if (rc) return rc;
@@ -280,6 +283,30 @@ int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* s
 template <class Rows, class Edges>
 static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows, Edges&& edges, bool full = false) {
   const int R = rg->g.R;
+  if (tuning("ring_edges_main", 0)) {
+    // Variant (opt-in): edge rows on the caller's stream in front of the interior, only the exchange on the ring's
+    // stream.  Measured at N = 1 with self send / recv (profiles/r02_ring_dissect.txt): what a launch-step loses against
+    // one launch over all rows (1.92 ms) is NOT the exchange -- pack, RCCL and unpack together add nothing measurable --
+    // but the fork / join itself: one event record + wait pair each way per step costs 0.11 ms with the default schedule
+    // below and 0.18-0.20 ms with this one (device-scope release events change neither figure).
+    const bool prof = rg->profile != 0;
+    if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_edge0, main));
+    int rc = edges(main);
+    if (rc) return rc;
+    if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_edge1, main));
+    LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
+    LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
+    if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_main0, main));
+    rc = rows(edge_rows, R - edge_rows, main);
+    if (rc) return rc;
+    if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_main1, main));
+    rc = ring_exchange(rg, dst, nullptr, rg->edge, full);
+    if (rc) return rc;
+    if (prof) LBM_CHECK_HIP(hipEventRecord(rg->t_xchg1, rg->edge));
+    LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+    LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+    return LBM_OK;
+  }
   // edge stream starts after everything previously enqueued on main (src complete)
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
