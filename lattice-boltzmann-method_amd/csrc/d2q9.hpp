@@ -764,22 +764,12 @@ struct sw_full_strips : std::false_type {};
 template <class M>
 struct sw_full_strips<M, std::void_t<decltype(M::kFullStrips)>> : std::bool_constant<M::kFullStrips> {};
 __host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 : (D == 3 ? 3 : (D <= 5 ? 2 : 1)); }
-template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
-    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
-    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0,
-    int chunk_stride = 0) {
+// one wavefront's walk down its strip chunk: `wave` = its index among the strips x chunks of this part of the launch
+template <class Model, int D, bool NT_STORE, bool HAS_BC, bool PF2>
+__device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const double* __restrict__ po, const Geom& g,
+                                             const Model& m, int row_begin, int row_end, int rows_per_chunk, int strips,
+                                             int wave, int lane, const Bc& bc, int strip0, int chunk_stride) {
   constexpr int W = sw_strip_width(D, sw_full_strips<Model>::value);  // output columns per wave
-  // workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th block.  xcd_group = G > 0: consecutive
-  // blocks of one XCD take G consecutive strip groups, so the 128-B lines that neighbouring strips
-  // share (a strip's 64 columns start 8 doubles before a line boundary) are fetched once per L2
-  int blk = blockIdx.x;
-  if (xcd_group > 0) {
-    const int x = blk % 8, mth = blk / 8, win = 8 * xcd_group;
-    if ((mth / xcd_group + 1) * win <= (int)gridDim.x) blk = (mth / xcd_group) * win + x * xcd_group + mth % xcd_group;
-  }
-  const int wave = blk * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (wave >= n_waves) return;
   const int strip = strip0 + wave % strips, chunk = wave / strips;  // strips = those of this launch, from strip0 on
   // chunk_stride > rows_per_chunk: the chunks are row ranges apart from each other (both edge-row
   // ranges of a slab in one launch: chunk 0 = [row_begin, +rows), chunk 1 = [row_begin + stride, +rows))
@@ -848,6 +838,54 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)
     sw_iteration<Model, D, 0, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
     sw_iteration<Model, D, 1, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
     sw_iteration<Model, D, 2, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
+  }
+}
+
+template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false>
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
+    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
+    int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0,
+    int chunk_stride = 0) {
+  // workgroup b runs on XCD b % 8 as that XCD's (b / 8)-th block.  xcd_group = G > 0: consecutive
+  // blocks of one XCD take G consecutive strip groups, so the 128-B lines that neighbouring strips
+  // share (a strip's 64 columns start 8 doubles before a line boundary) are fetched once per L2
+  int blk = blockIdx.x;
+  if (xcd_group > 0) {
+    const int x = blk % 8, mth = blk / 8, win = 8 * xcd_group;
+    if ((mth / xcd_group + 1) * win <= (int)gridDim.x) blk = (mth / xcd_group) * win + x * xcd_group + mth % xcd_group;
+  }
+  const int wave = blk * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wave >= n_waves) return;
+  sw_wave_body<Model, D, NT_STORE, HAS_BC, PF2>(pn, po, g, m, row_begin, row_end, rows_per_chunk, strips, wave, lane, bc, strip0, chunk_stride);
+}
+
+// Wall-bounded launch in ONE dispatch: the few waves of the frame (outermost strips, rows next to a wall row) run the
+// wall-carrying body, all others the plain one.  Both instantiations live in one kernel, whose register budget is the
+// larger one's -- no loss: at D >= 4 either runs one wave per SIMD anyway.  Frame waves come first in the grid.  (The
+// two-launch form forks the frame onto a helper stream and joins it: that event pair alone costs ~0.1 ms per launch,
+// profiles/r02_ring_dissect.txt.)
+struct SwPart {
+  int r0, r1, s0, ns, rpc, wave0;  // rows [r0, r1) x strips [s0, s0 + ns) in chunks of rpc rows; first wave of the part
+};
+struct SwParts {
+  SwPart p[5];  // 0..3: frame (left strips, right strips, top rows, bottom rows), 4: interior
+  int n_frame_waves, n_waves;
+};
+template <class Model, int D, bool NT_STORE>
+__global__ __launch_bounds__(128, 1) void k_stream_collide_sw_walls(double* __restrict__ pn, const double* __restrict__ po,
+                                                                    Geom g, Model m, Bc bc, SwParts parts) {
+  const int wave = blockIdx.x * 2 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wave >= parts.n_waves) return;
+  if (wave < parts.n_frame_waves) {
+    int k = 0;
+#pragma unroll
+    for (int a = 1; a < 4; ++a)
+      if (parts.p[a].ns > 0 && parts.p[a].r1 > parts.p[a].r0 && wave >= parts.p[a].wave0) k = a;
+    const SwPart pt = parts.p[k];
+    sw_wave_body<Model, D, NT_STORE, true, false>(pn, po, g, m, pt.r0, pt.r1, pt.rpc, pt.ns, wave - pt.wave0, lane, bc, pt.s0, 0);
+  } else {
+    const SwPart pt = parts.p[4];
+    sw_wave_body<Model, D, NT_STORE, false, false>(pn, po, g, m, pt.r0, pt.r1, pt.rpc, pt.ns, wave - pt.wave0, lane, bc, pt.s0, 0);
   }
 }
 

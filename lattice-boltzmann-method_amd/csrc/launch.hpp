@@ -271,8 +271,42 @@ int sw_launch_walls(double* pn, const double* po, const Geom& g, const Model& m,
     s1 = (g.C - W - DV) / W + 1;  // last strip with s W + W - 1 + (D - 1) <= C - 2
     if (s1 > strips) s1 = strips;
   }
-  if (tuning("sw_split", 1) == 0 || ra >= rb || s0 >= s1) {
+  // frame / interior split: 1 = two launches (frame first, on a helper stream: it runs BESIDE the interior, at the price of
+  // an event fork / join, ~0.1 ms), 2 = one dispatch holding both instantiations (no events; the interior compiled inside the
+  // larger register budget runs ~3 % slower).  Measured (profiles/r02_walls_split.log): a whole wall-bounded 8192^2 block 158.0 k
+  // MLUPS with 1, 153.7 k with 2; the far rows of an immersed-boundary block (two such launches per block beside the band
+  // chain) 94.5 k / 55.7 k / 34.7 k with 1, 102.2 k / 62.9 k / 42.4 k with 2 (16384x4096 / 4096^2 / 2048x4096); the Poiseuille
+  // channel's far rows 150.6 k with 1, 156.1 k with 2.  Default: 1 for a launch over a whole single block, 2 for row ranges.
+  int split = tuning("sw_split", -1);
+  if (split < 0) split = (row_begin == 0 && row_end == g.R && !g.ghost) ? 1 : 2;
+  if (split == 0 || ra >= rb || s0 >= s1) {
     sw_launch_part<Model, DV, true>(pn, po, g, m, bc, row_begin, row_end, 0, strips, 0, st);
+    return LBM_OK;
+  }
+  if (split == 2) {  // frame and interior in ONE dispatch (d2q9.hpp k_stream_collide_sw_walls)
+    SwParts pp{};
+    const int fr = 8;  // frame chunks: 8 rows after 2 (D - 1) warm-up rows, as in the two-launch form
+    auto part = [&](int k, int r0, int r1, int s0f, int ns, int rpc, int& wave0) {
+      if (r1 < r0) r1 = r0;
+      if (ns < 0) ns = 0;
+      if (rpc > r1 - r0) rpc = r1 - r0;
+      pp.p[k] = SwPart{r0, r1, s0f, ns, rpc > 0 ? rpc : 1, wave0};
+      if (r1 > r0 && ns > 0) wave0 += ns * ((r1 - r0 + pp.p[k].rpc - 1) / pp.p[k].rpc);
+    };
+    int w0 = 0;
+    part(0, row_begin, row_end, 0, s0, fr, w0);
+    part(1, row_begin, row_end, s1, strips - s1, fr, w0);
+    part(2, row_begin, ra, s0, s1 - s0, fr, w0);
+    part(3, rb, row_end, s0, s1 - s0, fr, w0);
+    pp.n_frame_waves = w0;
+    int rpc = tuning("sw_rows", -1);
+    if (rpc <= 0) {
+      const long slots = sw_wave_slots((const void*)k_stream_collide_sw_walls<Model, DV, true>, 128);
+      rpc = slots > 0 ? sw_pick_rows(rb - ra, s1 - s0, DV, slots) : 64;
+    }
+    part(4, ra, rb, s0, s1 - s0, rpc, w0);
+    pp.n_waves = w0;
+    LBM_KLAUNCH((k_stream_collide_sw_walls<Model, DV, true>), dim3((pp.n_waves + 1) / 2), dim3(128), 0, st, pn, po, g, m, bc, pp);
     return LBM_OK;
   }
   SwSideStream* sd = sw_side_stream();

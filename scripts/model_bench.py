@@ -168,10 +168,13 @@ if __name__ == "__main__":
             if rows:
                 bc.row_lo = bc.row_hi = pylbm.EDGE_BOUNCE_BACK
             for depth in os.environ.get("LBM_WALL_DEPTH", "5,1").split(","):
-                lib.set_tuning(b"solver_depth", int(depth))
-                lib.set_tuning(b"solver_depth_walls", int(depth))
-                bench_single(pylbm.MODEL_BGK, "BGK %s, %s step(s) per launch" % (name, depth), 8192, 8192,
-                             pylbm.BgkParams(1.2, 0), bc=bc)
+                for split in os.environ.get("LBM_WALL_SPLIT", "-1").split(","):
+                    lib.set_tuning(b"solver_depth", int(depth))
+                    lib.set_tuning(b"solver_depth_walls", int(depth))
+                    lib.set_tuning(b"sw_split", int(split))
+                    bench_single(pylbm.MODEL_BGK, "BGK %s, %s step(s) per launch, sw_split %s" % (name, depth, split), 8192, 8192,
+                                 pylbm.BgkParams(1.2, 0), bc=bc)
+            lib.set_tuning(b"sw_split", -1)
             lib.set_tuning(b"solver_depth", -1)
             lib.set_tuning(b"solver_depth_walls", -1)
     if "pressure" in which:   # Poiseuille channel at config-2 size: pressure-periodic rows, bounce-back columns

@@ -643,7 +643,7 @@ def test_sliding_window_carries_walls(lib, oracle, case):
                 src, a = a, src
             # split = 1 (default): wall-free interior through the plain instantiation, frame through the
             # wall-carrying one on the helper stream; 0: one wall-carrying launch
-            for rows, split in ((64, 1), (24, 1), (-1, 1), (64, 0)):
+            for rows, split in ((64, 1), (24, 1), (-1, 1), (64, 0), (64, 2), (24, 2), (-1, 2)):   # 2: frame + interior in ONE dispatch (the default)
                 lib.set_tuning(b"sw_rows", rows)
                 lib.set_tuning(b"sw_split", split)
                 b.zero_()
