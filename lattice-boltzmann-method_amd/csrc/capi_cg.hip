@@ -107,6 +107,12 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     return LBM_OK;
   }
   const int inner = (rc.ir1 - rc.ir0) * (rc.ic1 - rc.ic0), frame = tiles - inner;
+  if (frame > 0 && !tuning("cg_strip2", 0) && tuning("cg_merge", 0)) {  // frame + inner tiles in one dispatch (opt-in: measured level with the two-launch form, 15.24 k either way)
+    if (psi) LBM_KLAUNCH((k_cg_fused_merged<TR, TC, WAVES, true>), dim3(frame + inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc, frame);
+    else LBM_KLAUNCH((k_cg_fused_merged<TR, TC, WAVES, false>), dim3(frame + inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc, frame);
+    LBM_CHECK_LAUNCH();
+    return LBM_OK;
+  }
   // the frame (3-4 % of the tiles, latency-bound: 63 us on its own) goes FIRST and on the helper stream, so
   // that it runs beside the inner launch instead of behind it (fork / join through two events, launch.hpp)
   SwSideStream* sd = frame > 0 && tuning("cg_frame_beside", 1) ? sw_side_stream() : nullptr;

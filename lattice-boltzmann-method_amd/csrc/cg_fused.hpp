@@ -262,13 +262,13 @@ __device__ __forceinline__ void cg_collide_store(
 struct CgTileRect {
   int ir0, ir1, ic0, ic1;
 };
-template <int TR, int TC, int WAVES, bool WITH_FIELDS, int MODE = 0>
-__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
+template <int TR, int TC, bool WITH_FIELDS, int MODE>
+__device__ __forceinline__ void cg_fused_body(
     double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
+    const double* __restrict__ in_b, const Geom& g, const Bc& bc, const CgFast& cf, double* __restrict__ rho_r_out,
     double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle,
-    CgTileRect rect = CgTileRect{0, 0, 0, 0}) {
+    double* __restrict__ snu_out, const MacroIdx& mi, int row_begin, int row_end, int xcd_swizzle,
+    const CgTileRect& rect, int block_index, int grid_size) {
 #pragma clang fp contract(on)
   constexpr int NT = TR * TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
   constexpr bool INNER = MODE == 1;
@@ -278,9 +278,9 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
   // each with its own L2.  Neighbouring tiles share their +-3 ring (and, at 128-B lines, whole
   // cache lines on both sides of a 32-column tile: 2x read amplification when every XCD fetches
   // them on its own), so XCD k gets the k-th contiguous eighth of the tile sequence.
-  int tile = blockIdx.x;
+  int tile = block_index;
   if (xcd_swizzle == 1) {  // XCD k gets the k-th contiguous eighth of the tile sequence
-    const int per = gridDim.x / 8;
+    const int per = grid_size / 8;
     if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
   } else if (xcd_swizzle > 1) {
     // groups of G column-neighbour tiles per XCD, all XCDs inside the same window of 8 G tiles:
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
     // keep streaming through the same region of the lattice
     const int G = xcd_swizzle, x = tile % 8, m = tile / 8, win = 8 * G;
     const int t2 = (m / G) * win + x * G + (m % G);
-    if ((m / G + 1) * win <= (int)gridDim.x) tile = t2;
+    if ((m / G + 1) * win <= (int)grid_size) tile = t2;
   }
   int tile_r = tile / tiles_c, tile_c = tile % tiles_c;
   if (MODE == 1) {
@@ -365,6 +365,35 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
 
   cg_collide_store<WITH_FIELDS>(ft, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out,
                                 rho_b_out, u_out, psi_out, snu_out);
+}
+
+template <int TR, int TC, int WAVES, bool WITH_FIELDS, int MODE = 0>
+__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle,
+    CgTileRect rect = CgTileRect{0, 0, 0, 0}) {
+  cg_fused_body<TR, TC, WITH_FIELDS, MODE>(pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r_out, rho_b_out, u_out, psi_out, snu_out, mi,
+                                           row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// frame tiles and inner tiles in ONE dispatch: workgroups [0, n_frame) run the frame instantiation (general boundary
+// gather), the rest the inner one (plain offsets).  The two-launch form either runs the frame behind the inner launch
+// (63 us) or beside it on a helper stream, whose event fork / join costs as much as it hides (profiles/r02_ring_dissect.txt).
+template <int TR, int TC, int WAVES, bool WITH_FIELDS>
+__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused_merged(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle, CgTileRect rect,
+    int n_frame) {
+  if ((int)blockIdx.x < n_frame)
+    cg_fused_body<TR, TC, WITH_FIELDS, 2>(pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r_out, rho_b_out, u_out, psi_out, snu_out, mi,
+                                          row_begin, row_end, 0, rect, (int)blockIdx.x, n_frame);
+  else
+    cg_fused_body<TR, TC, WITH_FIELDS, 1>(pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r_out, rho_b_out, u_out, psi_out, snu_out, mi,
+                                          row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x - n_frame, (int)gridDim.x - n_frame);
 }
 
 // ---- column-strip sliding window --------------------------------------------------------------

@@ -119,8 +119,11 @@ def bench_cg(R, C, n=20):
             lib.set_tuning(b"cg_fused", 1)
             lib.set_tuning(b"cg_tile", int(tile))
             lib.set_tuning(b"cg_xcd", int(xcd))
-            dt = timed(lambda k: sv.step(k), n, warm=3)
-            report("colour-gradient MRT (fused, one launch per step, tile %s, xcd order %s)" % (tile, xcd), R, C, dt, 288)
+            for mg in os.environ.get("LBM_CG_MERGE", "-1").split(","):
+                lib.set_tuning(b"cg_merge", int(mg))
+                dt = timed(lambda k: sv.step(k), n, warm=3)
+                report("colour-gradient MRT (fused, one launch per step, tile %s, xcd order %s, merge %s)" % (tile, xcd, mg), R, C, dt, 288)
+            lib.set_tuning(b"cg_merge", -1)
     lib.set_tuning(b"cg_xcd", -1)
     lib.set_tuning(b"cg_fused", 0)
     dt = timed(lambda k: sv.step(k), n, warm=3)
