@@ -184,8 +184,7 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   double* lats[2] = {lattice, lattice2};
   const int nl = lattice2 ? 2 : 1;
   const size_t count = msg * nl;
-  const int skip = tuning("ring_debug_skip", 0);  // diagnosis only: 1 = no pack / unpack, 2 = no RCCL, 3 = neither (results wrong)
-  for (int k = 0; k < nl && !(skip & 1); ++k) {
+  for (int k = 0; k < nl; ++k) {
     if (rg->next >= 0) {
       int rc = lbm_halo_pack(rg->send_next + k * msg, lats[k], &rg->g, G, 1, rg->edge);
       if (rc) return rc;
@@ -195,7 +194,6 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
       if (rc) return rc;
     }
   }
-  if (!(skip & 2)) {
   LBM_CHECK_NCCL(g_rccl.GroupStart());
   // sends (to next, to prev), receives (from prev, from next): with two ranks both neighbours
   // are the same peer and messages match in issue order
@@ -204,8 +202,7 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_prev, count, kNcclFloat64, rg->prev, rg->comm, rg->edge));
   if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_next, count, kNcclFloat64, rg->next, rg->comm, rg->edge));
   LBM_CHECK_NCCL(g_rccl.GroupEnd());
-  }
-  for (int k = 0; k < nl && !(skip & 1); ++k) {
+  for (int k = 0; k < nl; ++k) {
     if (rg->prev >= 0) {
       int rc = lbm_halo_unpack(lats[k], rg->recv_prev + k * msg, &rg->g, G, 0, rg->edge);
       if (rc) return rc;

@@ -46,11 +46,5 @@ for rep in range(2):
     for name, fn in (("one launch over all rows", plain), ("edge launch + interior launch, no exchange", split_no_exchange), ("ring launch-step (self exchange)", ring)):
         ms = timeit(fn)
         print(f"{name:50s} {ms:.4f} ms per launch = {8192 * 8192 * D / ms / 1e3:.0f} MLUPS", flush=True)
-    if os.environ.get("RING_DISSECT"):
-        for skip, what in ((3, "ring step: fork / join only"), (2, "ring step: + pack / unpack, no RCCL"), (1, "ring step: + RCCL, no pack / unpack"), (0, "ring step: everything")):
-            for sched in (1, 0):
-                lib.set_tuning(b"ring_debug_skip", skip); lib.set_tuning(b"ring_edges_main", sched)
-                ms = timeit(ring)
-                print(f"{what:42s} edges_on_main={sched} {ms:.4f} ms per launch = {8192 * 8192 * D / ms / 1e3:.0f} MLUPS", flush=True)
-        lib.set_tuning(b"ring_debug_skip", 0); lib.set_tuning(b"ring_edges_main", -1)
-box.close()
+    # (the dissection behind profiles/r02_ring_dissect.txt -- the step with its pack / unpack kernels and / or the RCCL call
+    #  taken out -- used a diagnostic switch in capi_ring.hip that was removed again: it produced wrong results by design)
