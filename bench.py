@@ -106,7 +106,9 @@ class Box:
         self.prm = pylbm.BgkParams(a.omega, 0)
         self.bc = pylbm.Bc.periodic()
         self.depth = a.xn if (a.xn >= 2 and C >= 64 and R >= max(4 * a.xn + 8, 4 * a.edge_rows)) else 1
-        self.ghost = self.depth if with_ring else 0
+        # ghost = period x D rows: the ring exchanges once per `period` launches (capi_ring.hip ring_bgk_step)
+        self.period = max(1, a.ring_period) if (with_ring and self.depth > 1) else 1
+        self.ghost = self.depth * self.period if with_ring else 0
         rows = R + 2 * self.ghost
         pad = a.plane_pad if a.plane_pad is not None else lib.default_plane_pad(rows, C)
         self.plane = rows * C + pad
@@ -257,6 +259,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure HBM traffic with rocprofv3 --pmc child runs (N = 1); report the committed profile's figure")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--ring-period", type=int, default=2,
+                    help="slab ring: launches per halo exchange (ghost rows = period x D; 1: exchange every launch)")
     ap.add_argument("--force-halo", action="store_true",
                     help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv every launch)")
     a = ap.parse_args()
@@ -330,7 +334,8 @@ def main():
         lib.ring_profile(box.ring, 1)
         acc = []
         for _ in range(5):
-            box.launch(D)
+            for _ in range(box.period):   # every `period` consecutive launches hold one with an exchange: that one is timed
+                box.launch(D)
             out4 = (ct.c_double * 4)()
             lib.ring_last_timing(box.ring, out4)
             acc.append(list(out4))
@@ -429,11 +434,11 @@ def main():
                        "rows_per_gpu": R, "cols": C, "global_rows": R * world,
                        "plane_pad_doubles": box.plane - (R + 2 * box.ghost) * C,
                        "parallelism": f"slab{world}" if world > 1 else "single",
-                       "transport": ("lbm_ring (csrc/capi_ring.hip): one RCCL send + recv per neighbour per launch on the "
+                       "transport": (f"lbm_ring (csrc/capi_ring.hip): one RCCL send + recv per neighbour per {box.period} launch(es) on the "
                                      "ring's own stream, interior rows on the caller's stream" if box.ring else None),
                        "halo": ("none" if not box.ghost else
                                 f"{9 * (box.ghost - 1) if box.ghost > 1 else 3} rows of C doubles per side per "
-                                f"{box.ghost} step(s) over RCCL send/recv")},
+                                f"{box.ghost} step(s) ({box.period} launch(es)) over RCCL send/recv")},
             "timing": {"protocol": f">= {a.min_warm_s} s of untimed launches after --warmup, then `repeats` batches of `steps` "
                                    "steps, each bracketed by barrier + synchronize, MAX over ranks; value = median batch",
                        "warm_steps_run": warm_steps,

@@ -407,7 +407,11 @@ int lbm_ring_exchange2(lbm_ring* rg, double* lattice_a, double* lattice_b, lbm_s
 /* make `main` wait for the ring's stream */
 int lbm_ring_join(lbm_ring* rg, lbm_stream_t main);
 /* one overlapped launch-step of a BGK slab: n_steps = 1 (single-step kernel) or 2..ghost (sliding
- * window); bc: the physical edges of the GLOBAL domain (NULL = periodic), seams become HALO */
+ * window); bc: the physical edges of the GLOBAL domain (NULL = periodic), seams become HALO.
+ * On a closed (periodic) ring whose slabs carry ghost = m x n_steps rows (m = 2, 3; ghost <= 15) only
+ * every m-th call exchanges -- all m x n_steps ghost rows in one message; the calls in between are one
+ * plain launch over the owned rows plus the ghost rows the later calls of the period still read.  The
+ * owned rows are current after EVERY call; any lbm_ring_exchange* starts a new period. */
 int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
                       const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
 /* the same for KBC (n_steps 1, or 2..4 with the reassociated collision) */
@@ -598,7 +602,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * 1: they may use the reassociated model too, 1e-10 instead of bitwise on the cylinder preset), "ibm_depth" (steps lbm_solver_step advances per block on a BGK lattice with an immersed boundary: forced
  * band around the ROI in single steps, rows at least that far away through the multi-step window; default 5,
  * 1 = one step per launch everywhere; same bits), "pressure_depth" (steps per block on lattices with pressure-periodic rows: the 2 D rows on either side of the virtual rows in single steps on a small periodic
- * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
+ * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ring_period" (1: lbm_ring_bgk_step exchanges on every launch even when the slabs carry m x n_steps ghost rows; default 0 = one exchange per m launches), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
  * forcing workgroup is resident; 0: off), "sw_split" (1 [default]: wall-bounded
  * multi-step launches run their wall-free interior through the plain instantiation and only the frame of
  * outermost strips / rows next to a wall row through the wall-carrying one, on a helper stream; 0: one

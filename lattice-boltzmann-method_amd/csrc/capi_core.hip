@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void k_collision(double* __restrict__ fc,
 // message per neighbour.
 struct HaloTable {
   int n;             // rows in the message
-  short q[80];       // population of row i
-  short row[80];     // lattice row (owned-row index space; ghost rows negative / >= R) of row i
+  short q[136];      // population of row i
+  short row[136];     // lattice row (owned-row index space; ghost rows negative / >= R) of row i
 };
 // VEC = 2: 16 bytes per lane (C even, planes and buffers 16-byte aligned).  The launch is capped at a
 // few hundred workgroups ("halo_grid"): these copies run beside a grid-filling interior launch, where
@@ -203,7 +203,7 @@ static int halo_table(HaloTable& t, int depth_code, int side, bool sender, int R
     if (sender) row = (side == 1) ? R - 1 - k : k;
     else row = (side == 0) ? -1 - k : R + k;
     for (int j = 0; j < np; ++j) {
-      if (t.n >= 80) return -1;
+      if (t.n >= 136) return -1;
       t.q[t.n] = pops[j];
       t.row[t.n] = (short)row;
       ++t.n;
@@ -225,7 +225,7 @@ int lbm_halo_rows(int depth) {
 
 int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int depth, int side,
                   lbm_stream_t s) {
-  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE || (depth >= 101 && depth <= 108)) && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
+  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 15) || depth == LBM_HALO_TWO_PHASE || (depth >= 101 && depth <= 115)) && (side == 0 || side == 1), "lbm_halo_pack: bad argument");
   {
     const int need = depth == LBM_HALO_TWO_PHASE ? 3 : (depth >= 100 ? depth - 100 : depth);
     LBM_REQUIRE(g->ghost >= need && g->R >= need && g->R < 32000, "lbm_halo_pack: ghost=%d R=%d vs depth %d", g->ghost, g->R, need);
@@ -240,7 +240,7 @@ int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int dep
 
 int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int depth, int side,
                     lbm_stream_t s) {
-  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 8) || depth == LBM_HALO_TWO_PHASE || (depth >= 101 && depth <= 108)) && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
+  LBM_REQUIRE(buf && lattice && g && ((depth >= 1 && depth <= 15) || depth == LBM_HALO_TWO_PHASE || (depth >= 101 && depth <= 115)) && (side == 0 || side == 1), "lbm_halo_unpack: bad argument");
   {
     const int need = depth == LBM_HALO_TWO_PHASE ? 3 : (depth >= 100 ? depth - 100 : depth);
     LBM_REQUIRE(g->ghost >= need && g->R >= need && g->R < 32000, "lbm_halo_unpack: ghost=%d R=%d vs depth %d", g->ghost, g->R, need);

@@ -88,6 +88,7 @@ struct lbm_ring {
   hipEvent_t main_done, edge_done, aux_done;
   double *send_next, *send_prev, *recv_prev, *recv_next;
   // lbm_ring_profile(1): timed events around the three phases of the last launch-step
+  int phase;                     // launches since the last exchange (ghost = m x steps: one exchange per m launches)
   int profile;
   hipEvent_t t_edge0, t_edge1, t_xchg1, t_main0, t_main1;
 };
@@ -110,7 +111,7 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
                     const lbm_geom* slab, int periodic) {
   LBM_REQUIRE(out && id128 && slab, "lbm_ring_create: NULL argument");
   LBM_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "lbm_ring_create: rank %d of %d", rank, nranks);
-  LBM_REQUIRE(slab->ghost >= 1 && slab->ghost <= 8, "lbm_ring_create: slab needs 1..8 ghost rows (ghost=%d)", slab->ghost);
+  LBM_REQUIRE(slab->ghost >= 1 && slab->ghost <= 15, "lbm_ring_create: slab needs 1..15 ghost rows (ghost=%d)", slab->ghost);
   int rc = load_rccl();
   if (rc) return rc;
   lbm_ring* rg = new (std::nothrow) lbm_ring();
@@ -177,6 +178,7 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   // two lattices = the two colours; full = complete ghost rows (multi-step launches with walls)
   const int G = lattice2 ? LBM_HALO_TWO_PHASE : (full ? LBM_HALO_FULL(rg->g.ghost) : rg->g.ghost);
   const size_t msg = (size_t)lbm_halo_rows(G) * rg->g.C;
+  rg->phase = 0;  // every ghost row is current again
   if (as_stream(after) != rg->edge) {
     LBM_CHECK_HIP(hipEventRecord(rg->main_done, as_stream(after)));
     LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
@@ -326,12 +328,8 @@ static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main,
   return LBM_OK;
 }
 
-extern "C" {
-
-// BGK: n_steps = 1: single-step kernel (ghost >= 1); n_steps >= 2: sliding-window kernel
-// (ghost >= n_steps).
-int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
-                      const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s) {
+static int ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                         const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s, bool may_skip) {
   LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_bgk_step: NULL argument");
   const int R = rg->g.R, G = rg->g.ghost;
   LBM_REQUIRE(n_steps >= 1 && n_steps <= G, "lbm_ring_bgk_step: %d steps with %d ghost rows", n_steps, G);
@@ -340,6 +338,24 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
   if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
   if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  // ghost = m x n_steps on a closed ring: ONE exchange per m launches.  What a launch with an exchange costs over a
+  // plain launch is the fork / join of the two streams (0.11 ms, profiles/r02_ring_dissect.txt), not the bytes, so the
+  // m - 1 launches in between run as ONE plain launch on the caller's stream over the owned rows plus the ghost rows
+  // the later launches of the period still read (n_steps fewer per side each time; 2 x 5 extra rows in 1024 at m = 2),
+  // and the last one is the overlapped launch-step below with all m x n_steps ghost rows in the message.  Every rank
+  // takes the same branch: the decision depends on the ring's shape and on the call sequence only.
+  const int m = (may_skip && n_steps > 1 && rg->prev >= 0 && rg->next >= 0 && tuning("ring_period", 0) != 1) ? G / n_steps : 1;
+  if (m > 1) {
+    const int left = m - 1 - rg->phase;  // launches after this one before the next exchange
+    if (left > 0) {
+      lbm_geom g2 = rg->g;
+      g2.plane_stride = make_geom(rg->g).plane;
+      g2.R = R + 2 * left * n_steps;
+      g2.ghost = G - left * n_steps;
+      ++rg->phase;
+      return lbm_bgk_stream_collide_xn(dst, src, &g2, &b, prm, n_steps, 0, g2.R, main_s);
+    }
+  }
   // walls + several steps per launch: the NEXT launch reads complete ghost rows
   const bool full = n_steps > 1 && (bc_is_wall(b.row_lo) || bc_is_wall(b.row_hi) || bc_is_wall(b.col_lo) || bc_is_wall(b.col_hi));
   auto rows = [&](int r0, int r1, hipStream_t st) -> int {
@@ -352,6 +368,15 @@ int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
     return rc ? rc : rows(R - edge_rows, R, st);
   };
   return ring_step(rg, dst, edge_rows, as_stream(main_s), rows, edges, full);
+}
+
+extern "C" {
+
+// BGK: n_steps = 1: single-step kernel (ghost >= 1); n_steps >= 2: sliding-window kernel
+// (ghost >= n_steps; ghost = m x n_steps on a closed ring: one exchange per m launches).
+int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
+                      const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s) {
+  return ring_bgk_step(rg, dst, src, bc, prm, n_steps, edge_rows, main_s, true);
 }
 
 // KBC: the same schedule (n_steps 1, or 2..4 through the sliding window with the reassociated
@@ -554,7 +579,8 @@ int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const do
               "lbm_ring_bgk_block_ibm: ring and slab geometries differ (ghost rows must equal the block depth)");
   LBM_REQUIRE((!sl->has_prev || rg->prev >= 0) && (!sl->has_next || rg->next >= 0),
               "lbm_ring_bgk_block_ibm: the slab has a neighbour the ring does not know");
-  if (!sl->owner) return lbm_ring_bgk_step(rg, dst, src, &sl->bc_global, &sl->prm, sl->D, edge_rows, main_s);
+  // (every launch with its exchange: the band's co-owners exchange every block too)
+  if (!sl->owner) return ring_bgk_step(rg, dst, src, &sl->bc_global, &sl->prm, sl->D, edge_rows, main_s, false);
   hipStream_t main = as_stream(main_s);
   int rc = lbm_slab_ibm_block_compute(sl, dst, src, rg->send_prev, rg->send_next, main_s);
   if (rc) return rc;

@@ -13,7 +13,7 @@ namespace lbm {
 inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc, bool reads_neighbours = true) {
   LBM_REQUIRE(g, "%s: NULL geometry", fn);
   LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
-  LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 8, "%s: ghost=%d must be 0..8", fn, g->ghost);
+  LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 15, "%s: ghost=%d must be 0..15", fn, g->ghost);
   LBM_REQUIRE(g->plane_stride == 0 || g->plane_stride >= (long long)(g->R + 2 * g->ghost) * g->C,
               "%s: plane_stride=%lld smaller than a plane", fn, g->plane_stride);
   if (bc) {

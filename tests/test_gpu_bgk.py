@@ -868,3 +868,122 @@ def test_paired_strip_and_deep_prefetch_windows_bit_identical(lib, oracle, R, C)
     finally:
         for k in (b"sw_pair", b"sw_pf2", b"sw_rows"):
             lib.set_tuning(k, -1)
+
+
+@pytest.mark.parametrize("walls", [False, True])
+@pytest.mark.parametrize("period,launches", [(2, 4), (2, 3), (3, 7)])
+def test_native_ring_one_exchange_per_several_launches(lib, oracle, walls, period, launches):
+    """lbm_ring_bgk_step on a closed ring whose slabs carry ghost = period x D rows: only every period-th
+    launch exchanges (period x D rows deep); the launches in between run as ONE plain launch over the owned
+    rows plus the ghost rows the later launches of the period still read.  One rank, self send / recv;
+    owned rows after any number of launches (also one that stops inside a period) == the single block
+    advanced by the same window kernel, bit for bit.  With bounce-back columns the message carries complete
+    ghost rows (LBM_HALO_FULL)."""
+    R, C, D = 128, 200, 4
+    G = period * D
+    f0 = random_state(oracle, R, C, seed=21)
+    prm = pylbm.BgkParams(1.2, 0)
+    bc = pylbm.Bc.periodic()
+    if walls:
+        bc.col_lo = bc.col_hi = pylbm.EDGE_BOUNCE_BACK
+    flat = pylbm.Geom(R, C, 0)
+    p0 = upload_soa(lib, f0)
+    a, b = p0.clone(), torch.empty_like(p0)
+    for _ in range(launches):
+        lib.bgk_stream_collide_xn(_ptr(b), _ptr(a), ct.byref(flat), ct.byref(bc), ct.byref(prm), D, 0, R, None)
+        a, b = b, a
+    torch.cuda.synchronize()
+    g = pylbm.Geom(R, C, G)
+    lat = [torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+    lat[0][:, G:G + R] = p0
+    lat[1].fill_(float("nan"))          # nothing may be read that was not written
+    ident = (ct.c_ubyte * 128)()
+    ring = ct.c_void_p()
+    lib.ring_unique_id(ident)
+    lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
+    try:
+        torch.cuda.synchronize()
+        (lib.ring_exchange_full if walls else lib.ring_exchange)(ring, _ptr(lat[0]), None)
+        lib.ring_join(ring, None)
+        cur = 0
+        for _ in range(launches):
+            lib.ring_bgk_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), ct.byref(bc), ct.byref(prm), D, 16, None)
+            cur ^= 1
+        torch.cuda.synchronize()
+        got = lat[cur][:, G:G + R]
+        assert torch.equal(got, a), float((got - a).abs().max())
+        # "ring_period" = 1 switches the scheme off: every launch exchanges, same result
+        lib.set_tuning(b"ring_period", 1)
+        lat[0][:, G:G + R] = p0
+        torch.cuda.synchronize()
+        (lib.ring_exchange_full if walls else lib.ring_exchange)(ring, _ptr(lat[0]), None)
+        lib.ring_join(ring, None)
+        cur = 0
+        for _ in range(launches):
+            lib.ring_bgk_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), ct.byref(bc), ct.byref(prm), D, 16, None)
+            cur ^= 1
+        torch.cuda.synchronize()
+        assert torch.equal(lat[cur][:, G:G + R], a)
+    finally:
+        lib.set_tuning(b"ring_period", 0)
+        lib.ring_destroy(ring)
+
+
+@pytest.mark.parametrize("D,period", [(5, 2), (3, 3)])
+def test_three_slabs_one_exchange_per_several_launches(lib, oracle, D, period):
+    """The schedule of the ring with ghost = period x D rows, on three DIFFERENT slabs of a periodic box
+    emulated on one GPU (the self ring above cannot tell a slab from its neighbour): messages of the
+    partial depth-(period x D) halo (9 (period D - 1) rows) moved with lbm_halo_pack / _unpack, the
+    in-between launches over a widened geometry (owned rows + the ghost rows still needed), the last of
+    a period over the owned rows.  Equals the single block, bit for bit."""
+    Rg, C, S = 192, 128, 3
+    R, G = Rg // S, period * D
+    launches = 2 * period + 1
+    f0 = random_state(oracle, Rg, C, seed=5)
+    prm = pylbm.BgkParams(1.4, 0)
+    bc = pylbm.Bc.periodic()
+    flat = pylbm.Geom(Rg, C, 0)
+    p0 = upload_soa(lib, f0)
+    a, b = p0.clone(), torch.empty_like(p0)
+    for _ in range(launches):
+        lib.bgk_stream_collide_xn(_ptr(b), _ptr(a), ct.byref(flat), ct.byref(bc), ct.byref(prm), D, 0, Rg, None)
+        a, b = b, a
+    torch.cuda.synchronize()
+    geom = pylbm.Geom(R, C, G)
+    hb = pylbm.Bc.periodic()
+    hb.row_lo = hb.row_hi = pylbm.EDGE_HALO
+    lat = [[torch.full((9, R + 2 * G, C), float("nan"), dtype=torch.float64, device=dev()) for _ in range(2)] for _ in range(S)]
+    assert lib.raw.lbm_halo_rows(G) == 9 * (G - 1)
+    msg = torch.empty(lib.raw.lbm_halo_rows(G) * C, dtype=torch.float64, device=dev())
+
+    def halo(cur):
+        for s in range(S):
+            n = (s + 1) % S
+            lib.halo_pack(_ptr(msg), _ptr(lat[s][cur]), ct.byref(geom), G, 1, None)
+            lib.halo_unpack(_ptr(lat[n][cur]), _ptr(msg), ct.byref(geom), G, 0, None)
+            lib.halo_pack(_ptr(msg), _ptr(lat[n][cur]), ct.byref(geom), G, 0, None)
+            lib.halo_unpack(_ptr(lat[s][cur]), _ptr(msg), ct.byref(geom), G, 1, None)
+
+    for s in range(S):
+        lat[s][0][:, G:G + R] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    cur, phase = 0, 0
+    for _ in range(launches):
+        left = period - 1 - phase
+        for s in range(S):
+            if left > 0:
+                wide = pylbm.Geom(R + 2 * left * D, C, G - left * D, (R + 2 * G) * C)
+                lib.bgk_stream_collide_xn(_ptr(lat[s][cur ^ 1]), _ptr(lat[s][cur]), ct.byref(wide), ct.byref(hb),
+                                          ct.byref(prm), D, 0, R + 2 * left * D, None)
+            else:
+                lib.bgk_stream_collide_xn(_ptr(lat[s][cur ^ 1]), _ptr(lat[s][cur]), ct.byref(geom), ct.byref(hb),
+                                          ct.byref(prm), D, 0, R, None)
+        cur ^= 1
+        if left > 0:
+            phase += 1
+        else:
+            halo(cur)
+            phase = 0
+    torch.cuda.synchronize()
+    got = torch.cat([lat[s][cur][:, G:G + R] for s in range(S)], dim=1)
+    assert torch.equal(got, a), float((got - a).abs().max())
