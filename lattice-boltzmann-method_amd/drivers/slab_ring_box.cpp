@@ -6,7 +6,8 @@
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_box --id-file /tmp/x [...]   under any launcher
 //
 // Options: --rows R (per GPU, weak scaling) --cols C --steps K (launch-steps timed) --warmup W
-//          --depth D (time steps per launch = ghost rows, 1..6; KBC: 1..4) --edge-rows E --omega w
+//          --depth D (time steps per launch, 1..6; KBC: 1..4) --period P (BGK: launches per halo exchange,
+//          ghost rows = P x D; default 2) --edge-rows E --omega w
 //          --model bgk|kbc (kbc: the entropic KBC collision with s2 = omega, config 3 over slabs)
 //          --check 1 (N ranks vs rank 0 recomputing the whole box: small sizes only)
 //
@@ -49,7 +50,7 @@ void init_node(double* f9, int gr, int c, int Rg, int C) {
 }
 
 struct Args {
-  int rows = 8192, cols = 8192, steps = 20, warmup = 5, depth = 5, edge_rows = 32, check = 0;
+  int rows = 8192, cols = 8192, steps = 20, warmup = 5, depth = 5, period = 2, edge_rows = 32, check = 0;
   double omega = 1.2;
   bool kbc = false;
   std::string id_file;
@@ -87,7 +88,9 @@ double* make_slab(const Args& a, int R, int row0, int Rg, const lbm_geom& g, con
 int run_rank(const Args& a, int rank, int world, int local_rank) {
   check(lbm_set_device(local_rank), "lbm_set_device");
   const int R = a.rows, C = a.cols, D = a.depth, Rg = R * world;
-  lbm_geom g{R, C, D, 0};
+  // ghost = period x D rows: lbm_ring_bgk_step exchanges once per `period` launches (BGK; KBC: every launch)
+  const int G = D * ((a.kbc || D < 2) ? 1 : a.period);
+  lbm_geom g{R, C, G, 0};
   lbm_bgk_params prm{};
   prm.omega = a.omega;
   lbm_kbc_params kprm{a.omega};
@@ -102,7 +105,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   lbm_ring* ring = nullptr;
   check(lbm_ring_create(&ring, id, rank, world, &g, /*periodic=*/1), "lbm_ring_create");
 
-  const size_t plane = (size_t)(R + 2 * D) * C;
+  const size_t plane = (size_t)(R + 2 * G) * C;
   double* lat[2];
   lat[0] = make_slab(a, R, rank * R, Rg, g, prm);
   check(lbm_malloc((void**)&lat[1], 9 * plane * sizeof(double)), "lbm_malloc");
@@ -145,7 +148,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
     check(lbm_stream_sync(nullptr), "sync");
     std::vector<double> own((size_t)9 * R * C);
     for (int q = 0; q < 9; ++q)
-      std::memcpy(&own[(size_t)q * R * C], &h[q * plane + (size_t)D * C], (size_t)R * C * sizeof(double));
+      std::memcpy(&own[(size_t)q * R * C], &h[q * plane + (size_t)G * C], (size_t)R * C * sizeof(double));
     write_file_atomic(a.id_file + ".f" + std::to_string(rank), own.data(), own.size() * sizeof(double));
     if (rank == 0) {
       Args whole = a;
@@ -178,9 +181,9 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   if (rank == 0) {
     const double lups = (double)Rg * C * D * a.steps / tmax;
     std::printf("{\"driver\": \"slab_ring_box\", \"model\": \"%s\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, "
-                "\"depth\": %d, \"launches\": %d, \"ms_per_launch\": %.4f, \"mlups\": %.1f, "
+                "\"depth\": %d, \"ghost_rows\": %d, \"launches\": %d, \"ms_per_launch\": %.4f, \"mlups\": %.1f, "
                 "\"transport\": \"rccl send/recv (C++ ring)\"%s}\n",
-                a.kbc ? "kbc" : "bgk", world, R, C, D, a.steps, 1e3 * tmax / a.steps, lups / 1e6,
+                a.kbc ? "kbc" : "bgk", world, R, C, D, G, a.steps, 1e3 * tmax / a.steps, lups / 1e6,
                 a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
     std::fflush(stdout);
   }
@@ -199,6 +202,7 @@ int main(int argc, char** argv) {
   a.steps = std::atoi(arg_value(argc, argv, "--steps", "20").c_str());
   a.warmup = std::atoi(arg_value(argc, argv, "--warmup", "5").c_str());
   a.depth = std::atoi(arg_value(argc, argv, "--depth", "5").c_str());
+  a.period = std::max(1, std::min(3, std::atoi(arg_value(argc, argv, "--period", "2").c_str())));
   a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "32").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
   a.omega = std::atof(arg_value(argc, argv, "--omega", "1.2").c_str());

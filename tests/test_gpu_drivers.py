@@ -141,14 +141,16 @@ def test_slab_ring_box_driver_self_ring(tmp_path):
     import json
     exe = os.path.join(BIN, "slab_ring_box")
     assert os.path.exists(exe)
-    for depth, edge, model in ((5, 16, "bgk"), (1, 8, "bgk"), (3, 16, "kbc")):
+    for depth, edge, model, period in ((5, 16, "bgk", 2), (5, 16, "bgk", 1), (3, 16, "bgk", 3), (1, 8, "bgk", 2), (3, 16, "kbc", 2)):
         r = subprocess.run([exe, "--spawn", "1", "--rows", "160", "--cols", "256", "--steps", "3", "--model", model,
                             "--warmup", "1", "--depth", str(depth), "--edge-rows", str(edge), "--check", "1",
-                            "--id-file", str(tmp_path / f"id{depth}{model}")],
+                            "--period", str(period), "--id-file", str(tmp_path / f"id{depth}{model}{period}")],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["check"] == "bitwise equal to one block" and line["depth"] == depth
+        # BGK window launches: ghost = period x depth rows, one exchange per `period` launches
+        assert line["ghost_rows"] == (depth * period if model == "bgk" and depth > 1 else depth)
 
 
 def test_slab_ring_rt_driver(tmp_path):
