@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <new>
 #include <string>
 
@@ -167,6 +168,39 @@ static void launch_halo_copy(double* dst, const double* src, const Geom& gg, con
   const int cap = tuning("halo_grid", 256);
   if (v2) LBM_KLAUNCH(k_halo_copy<2>, dim3(capped_grid(((long)t.n * (gg.C / 2) + 255) / 256, cap)), dim3(256), 0, st, dst, src, gg, t, to_buffer);
   else LBM_KLAUNCH(k_halo_copy<1>, dim3(capped_grid(((long)t.n * gg.C + 255) / 256, cap)), dim3(256), 0, st, dst, src, gg, t, to_buffer);
+}
+
+__global__ __launch_bounds__(256) void k_box_copy(double* __restrict__ dst, Geom dg, int dr, int dc,
+                                                  const double* __restrict__ src, Geom sg, int sr, int sc,
+                                                  int nr, int nc) {
+  const long per = (long)nr * nc, n = 9 * per;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int q = (int)(i / per);
+    const long k = i % per;
+    const int r = (int)(k / nc), c = (int)(k % nc);
+    dst[q * dg.plane + dg.at(dr + r, dc + c)] = src[q * sg.plane + sg.at(sr + r, sc + c)];
+  }
+}
+int box_copy(double* dst, const lbm_geom& dg, int dst_row, int dst_col, const double* src, const lbm_geom& sg,
+             int src_row, int src_col, int n_rows, int n_cols, hipStream_t st) {
+  LBM_REQUIRE(dst && src && n_rows >= 0 && n_cols >= 0, "box_copy: bad argument");
+  LBM_REQUIRE(dst_row >= -dg.ghost && dst_row + n_rows <= dg.R + dg.ghost && dst_col >= 0 && dst_col + n_cols <= dg.C &&
+                  src_row >= -sg.ghost && src_row + n_rows <= sg.R + sg.ghost && src_col >= 0 && src_col + n_cols <= sg.C,
+              "box_copy: box outside a lattice");
+  if (n_rows == 0 || n_cols == 0) return LBM_OK;
+  LBM_KLAUNCH(k_box_copy, dim3(capped_grid((9L * n_rows * n_cols + 255) / 256, 1024)), dim3(256), 0, st, dst, make_geom(dg),
+              dst_row, dst_col, src, make_geom(sg), src_row, src_col, n_rows, n_cols);
+  LBM_CHECK_LAUNCH();
+  return LBM_OK;
+}
+int make_background_stream(hipStream_t* out) {
+  int lo = 0, hi = 0;  // (numerically: lo = least urgent)
+  if (tuning("bg_priority", 1) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+      hipStreamCreateWithPriority(out, hipStreamNonBlocking, lo) == hipSuccess)
+    return LBM_OK;
+  (void)hipGetLastError();
+  LBM_CHECK_HIP(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+  return LBM_OK;
 }
 
 // rows of the depth-D halo in message order.  side 1: towards the NEXT slab (c_x = +1 leave);

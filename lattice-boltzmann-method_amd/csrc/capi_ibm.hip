@@ -31,6 +31,15 @@ struct IbmDev {
   const int* tptr;     // [n_touched + 1] csr_ptr restricted to the touched nodes
   double Ubx, Uby;     // marker velocity U_b (0 in the reference: stationary boundary)
   int moving;          // U_b != 0
+  // the same tables laid out for k_ibm_step, where lane = marker (taps) and lane = touched node (pairs): consecutive
+  // lanes read consecutive words.  ([marker][16] and CSR make every lane of a load hit its own cache line: the one
+  // workgroup then spends its time in the texture addresser, 16 x more line requests than lines.)
+  const int* tap_k;    // [16][n_markers]
+  const double* phi_k; // [16][n_markers]
+  const int* ell_cnt;  // [n_touched] pairs of the node
+  const int* ell_mk;   // [ell_deg][n_touched] marker of pair s of the node (ascending), 0 beyond its count
+  const double* ell_w; // [ell_deg][n_touched]
+  int ell_deg;
 };
 
 // u, rho of the ROI window copied out of the full fields (ibm.cpp:163-164); F_sum = 0
@@ -121,6 +130,28 @@ __global__ __launch_bounds__(256) void k_ibm_add_source(IbmDev d, double* __rest
   }
 }
 
+// the same on the touched nodes only (F = 0 elsewhere: the source there is exactly 0), many workgroups
+__global__ __launch_bounds__(256) void k_ibm_add_source_touched(IbmDev d, double* __restrict__ p, Geom g,
+                                                                const double* __restrict__ u,
+                                                                const double* __restrict__ F_sum,
+                                                                double omega, double a, double b) {
+  const int n = d.RR * d.RC;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= d.n_touched) return;
+  const int i = d.touched[t];
+  const int r = d.r0 + i / d.RC, c = d.c0 + i % d.RC;
+  const long s = (long)r * d.Y + c, N = (long)d.X * d.Y;
+  const double ux = u[s], uy = u[N + s], Fx = F_sum[i], Fy = F_sum[n + i];
+  const double uF = ux * Fx + uy * Fy;
+  const long o = g.at(r, c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+    const double cF = Fx * (double)icx(q) + Fy * (double)icy(q);
+    p[q * g.plane + o] += ((1 - 0.5 * omega) * ((a + b * cu) * cF - a * uF) * wq(q));
+  }
+}
+
 // The whole forcing of one time step in ONE launch of ONE workgroup: eulerian_force_density
 // (ibm.cpp:158-190, all m_max - 1 iterations) followed by the driver's source term
 // (cylinder_test.cpp:116-127).  Only the nodes under a marker's 4x4 box ("touched", a band of a
@@ -130,6 +161,10 @@ __global__ __launch_bounds__(256) void k_ibm_add_source(IbmDev d, double* __rest
 // and the working set (u, rho of the touched nodes, f_j of the markers) lives in LDS.
 // Arithmetic per marker / per node is that of k_ibm_interp / k_ibm_spread / k_ibm_add_source in
 // the same order, so results are bit-identical.  Dynamic LDS: (3 n_touched + 2 n_markers) doubles.
+// OPT = 1 (default; "ibm_step_opt" = 0 selects the form of round 1, same bits): taps and (marker, weight) pairs are read
+// from the lane-major tables (IbmDev::tap_k ... ell_w), pairs 4 at a time; all sums keep their order.  The launch is one workgroup deep: its time IS its chain of
+// latencies (82 us -> see profiles/r02_ibm_force.txt).
+template <int OPT, int MAXOWN>
 __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const double* __restrict__ u,
                                                    const double* __restrict__ rho,
                                                    double* __restrict__ F_sum, double* __restrict__ p,
@@ -145,12 +180,15 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
   double* s_fj = lds + 3 * nt;   // [2 nm]
   const long N = (long)d.X * d.Y;
   // each thread owns the touched nodes t = tid, tid + 1024, ...: F accumulates in registers
-  constexpr int MAXOWN = 8;  // host guarantees nt <= 8 * 1024
+  // (MAXOWN: host guarantees nt <= MAXOWN * 1024)
   double Fx[MAXOWN], Fy[MAXOWN];
+  int cnt[MAXOWN];
+  constexpr int NB = 4;  // pairs fetched together (8: no faster)
 #pragma unroll
   for (int k = 0; k < MAXOWN; ++k) {
     Fx[k] = 0.0;
     Fy[k] = 0.0;
+    cnt[k] = 0;
     const int t = threadIdx.x + k * 1024;
     if (t < nt) {
       const int i = d.touched[t];
@@ -158,6 +196,7 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
       s_ux[t] = u[s];
       s_uy[t] = u[N + s];
       s_rho[t] = rho[s];
+      if (OPT) cnt[k] = d.ell_cnt[t];
     }
   }
   __syncthreads();
@@ -166,8 +205,8 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
       double ujx = 0.0, ujy = 0.0, rhoj = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const int t = d.tap_t[j * 16 + k];
-        const double w = d.phi[j * 16 + k];
+        const int t = OPT ? d.tap_k[k * nm + j] : d.tap_t[j * 16 + k];
+        const double w = OPT ? d.phi_k[k * nm + j] : d.phi[j * 16 + k];
         ujx += w * s_ux[t];
         ujy += w * s_uy[t];
         rhoj += w * s_rho[t];
@@ -181,22 +220,54 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
       }
     }
     __syncthreads();
+    if (OPT) {
 #pragma unroll
-    for (int k = 0; k < MAXOWN; ++k) {
-      const int t = threadIdx.x + k * 1024;
-      if (t < nt) {
+      for (int k = 0; k < MAXOWN; ++k) {
+        const int t = threadIdx.x + k * 1024;
         double fx = 0.0, fy = 0.0;
-        for (int e = d.tptr[t]; e < d.tptr[t + 1]; ++e) {
-          const int j = d.csr_mk[e];
-          const double w = d.csr_w[e];
-          fx += w * s_fj[j];
-          fy += w * s_fj[nm + j];
+        for (int s0 = 0; s0 < cnt[k]; s0 += NB) {  // (cnt = 0 for the slots this thread does not own)
+          const int c4 = cnt[k] - s0;
+          int jj[NB];
+          double ww[NB];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            jj[i] = i < c4 ? d.ell_mk[(s0 + i) * nt + t] : 0;
+            ww[i] = i < c4 ? d.ell_w[(s0 + i) * nt + t] : 0.0;
+          }
+#pragma unroll
+          for (int i = 0; i < NB; ++i) {
+            if (i < c4) {
+              fx += ww[i] * s_fj[jj[i]];
+              fy += ww[i] * s_fj[nm + jj[i]];
+            }
+          }
         }
-        const double rh = s_rho[t];
-        s_ux[t] += 0.5 * fx / rh;
-        s_uy[t] += 0.5 * fy / rh;
-        Fx[k] += fx;
-        Fy[k] += fy;
+        if (t < nt) {
+          const double rh = s_rho[t];
+          s_ux[t] += 0.5 * fx / rh;
+          s_uy[t] += 0.5 * fy / rh;
+          Fx[k] += fx;
+          Fy[k] += fy;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXOWN; ++k) {
+        const int t = threadIdx.x + k * 1024;
+        if (t < nt) {
+          double fx = 0.0, fy = 0.0;
+          for (int e = d.tptr[t]; e < d.tptr[t + 1]; ++e) {
+            const int j = d.csr_mk[e];
+            const double w = d.csr_w[e];
+            fx += w * s_fj[j];
+            fy += w * s_fj[nm + j];
+          }
+          const double rh = s_rho[t];
+          s_ux[t] += 0.5 * fx / rh;
+          s_uy[t] += 0.5 * fy / rh;
+          Fx[k] += fx;
+          Fy[k] += fy;
+        }
       }
     }
     __syncthreads();
@@ -268,8 +339,9 @@ struct lbm_ibm {
   bool gate_ok = false; // the last lbm_ibm_step went through that kernel
   lbm::IbmDev d;
   int m_max, r1, c1;
-  bool lds_opt_in = false;
+  unsigned lds_opt_in = 0;  // bit per k_ibm_step instantiation that has its dynamic-LDS limit raised
   void* dev_blob;                  // all constant device arrays in one allocation
+  void* dev_blob2;                 // their lane-major copies (k_ibm_step)
   double *u_roi, *rho_roi, *F_sum, *fj, *out2;  // device work arrays
 };
 
@@ -346,12 +418,33 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   for (size_t t = 0; t < touched.size(); ++t) tptr[t] = csr_ptr[touched[t]];
   tptr[touched.size()] = (int)nnz;
 
+  // lane-major copies for k_ibm_step
+  const size_t nt_ = touched.size();
+  int ell_deg = 0;
+  std::vector<int> ell_cnt(nt_);
+  for (size_t t = 0; t < nt_; ++t) {
+    ell_cnt[t] = tptr[t + 1] - tptr[t];
+    ell_deg = std::max(ell_deg, ell_cnt[t]);
+  }
+  std::vector<int> tap_k((size_t)16 * n_markers), ell_mk((size_t)ell_deg * nt_, 0);
+  std::vector<double> phi_k((size_t)16 * n_markers), ell_w((size_t)ell_deg * nt_, 0.0);
+  for (int j = 0; j < n_markers; ++j)
+    for (int k = 0; k < 16; ++k) {
+      tap_k[(size_t)k * n_markers + j] = tap_t[(size_t)j * 16 + k];
+      phi_k[(size_t)k * n_markers + j] = phi[(size_t)j * 16 + k];
+    }
+  for (size_t t = 0; t < nt_; ++t)
+    for (int s = 0; s < ell_cnt[t]; ++s) {
+      ell_mk[(size_t)s * nt_ + t] = csr_mk[tptr[t] + s];
+      ell_w[(size_t)s * nt_ + t] = csr_w[tptr[t] + s];
+    }
+
   lbm_ibm* ib = new (std::nothrow) lbm_ibm();
   LBM_REQUIRE(ib, "lbm_ibm_create: out of host memory");
   ib->m_max = m_max;
   ib->r1 = (int)r_max + 1 - row_offset;
   ib->c1 = (int)c_max + 1;
-  ib->dev_blob = nullptr;
+  ib->dev_blob = ib->dev_blob2 = nullptr;
   ib->u_roi = ib->rho_roi = ib->F_sum = ib->fj = ib->out2 = nullptr;
   // one blob: doubles first (8-byte aligned), then ints
   const size_t n_dbl = phi.size() + nnz, n_int = box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size() + tptr.size();
@@ -369,6 +462,20 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   std::copy(tptr.begin(), tptr.end(), hi + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size());
   hipError_t e = hipMalloc(&ib->dev_blob, blob_bytes);
   if (e == hipSuccess) e = hipMemcpy(ib->dev_blob, host.data(), blob_bytes, hipMemcpyHostToDevice);
+  // second blob: doubles (phi_k, ell_w), then ints (tap_k, ell_cnt, ell_mk)
+  const size_t n_dbl2 = phi_k.size() + ell_w.size(), n_int2 = tap_k.size() + ell_cnt.size() + ell_mk.size();
+  std::vector<char> host2(n_dbl2 * 8 + n_int2 * 4);
+  {
+    double* h2 = reinterpret_cast<double*>(host2.data());
+    std::copy(phi_k.begin(), phi_k.end(), h2);
+    std::copy(ell_w.begin(), ell_w.end(), h2 + phi_k.size());
+    int* i2 = reinterpret_cast<int*>(host2.data() + n_dbl2 * 8);
+    std::copy(tap_k.begin(), tap_k.end(), i2);
+    std::copy(ell_cnt.begin(), ell_cnt.end(), i2 + tap_k.size());
+    std::copy(ell_mk.begin(), ell_mk.end(), i2 + tap_k.size() + ell_cnt.size());
+  }
+  if (e == hipSuccess) e = hipMalloc(&ib->dev_blob2, host2.size());
+  if (e == hipSuccess) e = hipMemcpy(ib->dev_blob2, host2.data(), host2.size(), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc(&ib->u_roi, (size_t)n * 16);
   if (e == hipSuccess) e = hipMalloc(&ib->rho_roi, (size_t)n * 8);
   if (e == hipSuccess) e = hipMalloc(&ib->F_sum, (size_t)n * 16);
@@ -389,14 +496,24 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
                  di + box0.size(), di + box0.size() + csr_ptr.size(), dd + phi.size(),
                  di + box0.size() + csr_ptr.size() + nnz, (int)touched.size(),
                  di + box0.size() + csr_ptr.size() + nnz + touched.size(),
-                 di + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size(), 0.0, 0.0, 0};
+                 di + box0.size() + csr_ptr.size() + nnz + touched.size() + tap_t.size(), 0.0, 0.0, 0,
+                 nullptr, nullptr, nullptr, nullptr, nullptr, ell_deg};
+  {
+    const double* d2 = reinterpret_cast<const double*>(ib->dev_blob2);
+    const int* i2 = reinterpret_cast<const int*>(static_cast<char*>(ib->dev_blob2) + n_dbl2 * 8);
+    ib->d.phi_k = d2;
+    ib->d.ell_w = d2 + phi_k.size();
+    ib->d.tap_k = i2;
+    ib->d.ell_cnt = i2 + tap_k.size();
+    ib->d.ell_mk = i2 + tap_k.size() + ell_cnt.size();
+  }
   *out = ib;
   return LBM_OK;
 }
 
 int lbm_ibm_destroy(lbm_ibm* ib) {
   if (!ib) return LBM_OK;
-  for (void* p : {ib->dev_blob, (void*)ib->u_roi, (void*)ib->rho_roi, (void*)ib->F_sum,
+  for (void* p : {ib->dev_blob, ib->dev_blob2, (void*)ib->u_roi, (void*)ib->rho_roi, (void*)ib->F_sum,
                   (void*)ib->fj, (void*)ib->out2, (void*)ib->flag})
     if (p) (void)hipFree(p);
   delete ib;
@@ -459,27 +576,65 @@ int lbm_ibm_step(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, con
   LBM_REQUIRE(g->R == ib->d.X && g->C == ib->d.Y,
               "lbm_ibm_step: lattice %dx%d does not match the boundary's %dx%d", g->R, g->C, ib->d.X, ib->d.Y);
   const size_t lds = ((size_t)3 * ib->d.n_touched + 2 * (size_t)ib->d.n_markers) * sizeof(double);
-  if (ib->d.n_touched > 8 * 1024 || lds > 150 * 1024) {  // large boundaries: the launch chain
+  if (ib->d.n_touched > 8 * 1024 || lds > 150 * 1024 || tuning("ibm_step_chain", 0)) {  // large boundaries: the launch chain
     ib->gate_ok = false;
     int rc = lbm_ibm_force(ib, u, rho, nullptr, s);
     if (!rc) rc = lbm_ibm_add_source(ib, p, g, u, omega, a, b, s);
     return rc;
   }
-  if (!ib->lds_opt_in) {
-    LBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ibm_step),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    ib->lds_opt_in = true;
-  }
   ++ib->seq;
   ib->gate_ok = true;
-  LBM_KLAUNCH(k_ibm_step, dim3(1), dim3(1024), lds, as_stream(s), ib->d, ib->m_max, u, rho, ib->F_sum, p,
-              make_geom(*g), omega, a, b, 1, ib->flag, ib->seq);
+  const int own = ib->d.n_touched <= 4096 ? 4 : (ib->d.n_touched <= 6144 ? 6 : 8);  // touched nodes per thread
+  const int variant = (tuning("ibm_step_opt", 1) ? 10 : 0) + own;
+  // the source term as a second, many-workgroup launch: 9 scattered read-modify-writes per touched node from ONE
+  // compute unit cost 16 of the 60 us (profiles/r02_ibm_force.txt)
+  const bool split = tuning("ibm_step_split", 1) != 0;
+  auto go = [&](auto kern) -> int {
+    if (!(ib->lds_opt_in & (1u << (variant % 10 / 2 + (variant >= 10 ? 4 : 0))))) {
+      LBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      ib->lds_opt_in |= 1u << (variant % 10 / 2 + (variant >= 10 ? 4 : 0));
+    }
+    LBM_KLAUNCH(kern, dim3(1), dim3(1024), lds, as_stream(s), ib->d, ib->m_max, u, rho, ib->F_sum, p, make_geom(*g), omega,
+                a, b, split ? 0 : 1, ib->flag, ib->seq);
+    if (split)
+      LBM_KLAUNCH(k_ibm_add_source_touched, dim3((ib->d.n_touched + 255) / 256), dim3(256), 0, as_stream(s), ib->d, p,
+                  make_geom(*g), u, ib->F_sum, omega, a, b);
+    return LBM_OK;
+  };
+  int rc = LBM_OK;
+  switch (variant) {
+    case 4: rc = go(&k_ibm_step<0, 4>); break;
+    case 6: rc = go(&k_ibm_step<0, 6>); break;
+    case 8: rc = go(&k_ibm_step<0, 8>); break;
+    case 14: rc = go(&k_ibm_step<1, 4>); break;
+    case 16: rc = go(&k_ibm_step<1, 6>); break;
+    default: rc = go(&k_ibm_step<1, 8>); break;
+  }
+  if (rc) return rc;
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
 
 }  // extern "C"
 namespace lbm {
+int ibm_step_window(lbm_ibm* ib, int row_off, int col_off, double* p, const lbm_geom* g, const double* u,
+                    const double* rho, double omega, double a, double b, hipStream_t st) {
+  LBM_REQUIRE(ib && g, "ibm_step_window: NULL argument");
+  LBM_REQUIRE(ib->d.r0 - row_off >= 1 && ib->d.c0 - col_off >= 1 && ib->r1 - row_off <= g->R - 1 && ib->c1 - col_off <= g->C - 1,
+              "ibm_step_window: ROI outside the window");
+  lbm_ibm w = *ib;  // shares every device array; never destroyed
+  w.d.r0 -= row_off;
+  w.d.c0 -= col_off;
+  w.r1 -= row_off;
+  w.c1 -= col_off;
+  w.d.X = g->R;
+  w.d.Y = g->C;
+  const int rc = lbm_ibm_step(&w, p, g, u, rho, omega, a, b, reinterpret_cast<lbm_stream_t>(st));
+  ib->seq = w.seq;
+  ib->gate_ok = w.gate_ok;
+  ib->lds_opt_in = w.lds_opt_in;
+  return rc;
+}
 int ibm_gate(lbm_ibm* ib, hipStream_t st) {
   if (!ib || !ib->gate_ok || tuning("ibm_gate", 1) == 0) return LBM_OK;
   LBM_KLAUNCH(k_ibm_gate, dim3(1), dim3(64), 0, st, ib->flag, ib->seq, 4000);  // <= ~4 ms, then gives up

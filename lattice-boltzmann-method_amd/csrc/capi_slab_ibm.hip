@@ -60,10 +60,14 @@ int lbm_slab_ibm_destroy(lbm_slab_ibm* sl) {
     (void)hipStreamSynchronize(sl->aux);
     (void)hipStreamDestroy(sl->aux);
   }
+  if (sl->bgst) {
+    (void)hipStreamSynchronize(sl->bgst);
+    (void)hipStreamDestroy(sl->bgst);
+  }
   if (sl->ev_fork) (void)hipEventDestroy(sl->ev_fork);
   if (sl->ev_join) (void)hipEventDestroy(sl->ev_join);
   if (sl->ib) (void)lbm_ibm_destroy(sl->ib);
-  for (double* p : {sl->blat[0], sl->blat[1], sl->brho, sl->bu, sl->stash})
+  for (double* p : {sl->blat[0], sl->blat[1], sl->brho, sl->bu, sl->stash, sl->box[0], sl->box[1], sl->xrho, sl->xu})
     if (p) (void)hipFree(p);
   delete sl;
   return LBM_OK;
@@ -143,6 +147,21 @@ int lbm_slab_ibm_create(lbm_slab_ibm** out, const lbm_geom* slab, int slab_row0,
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&sl->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&sl->ev_join, hipEventDisableTiming);
+  // the forced box (lbm_slab_ibm_block_compute): only if it keeps clear of the wall columns
+  int q0r, q1r, c0, c1;
+  if (e == hipSuccess && lbm_ibm_roi(sl->ib, &q0r, &q1r, &c0, &c1) == LBM_OK && c0 - 2 * D >= 8 && (c1 + 2 * D + 7) / 8 * 8 <= C - 1) {
+    sl->bc0 = (c0 - 2 * D) / 8 * 8;
+    sl->bc1 = (c1 + 2 * D + 7) / 8 * 8;
+    const int Cb = sl->bc1 - sl->bc0;
+    sl->xg = lbm_geom{Rb, Cb, 0, (long long)Rb * Cb + 136};
+    const size_t xb = (size_t)sl->xg.plane_stride * 9 * sizeof(double), xn = (size_t)Rb * Cb;
+    for (double** p : {&sl->box[0], &sl->box[1]})
+      if (e == hipSuccess) e = hipMalloc(p, xb);
+    if (e == hipSuccess) e = hipMalloc(&sl->xrho, xn * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&sl->xu, 2 * xn * sizeof(double));
+    if (e == hipSuccess && make_background_stream(&sl->bgst) != LBM_OK) e = hipErrorUnknown;
+    sl->boxed = e == hipSuccess;
+  }
   if (e != hipSuccess) {
     set_error("lbm_slab_ibm_create: %s", hipGetErrorString(e));
     lbm_slab_ibm_destroy(sl);
@@ -290,7 +309,49 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
   hipStream_t st = as_stream(s);
   int rc = LBM_OK;
   int o0 = R, o1 = R;  // owned rows [o0, o1) come from the band; everything else is far
-  if (sl->owner) {
+  if (sl->owner && sl->boxed && tuning("ibm_box", 1)) {
+    // The forcing reaches a node only through the ROI, so the D forced single steps are cut to a BOX -- band rows x
+    // columns ROI +- 2 D -- held as a small periodic lattice pair of its own (what its wrap spoils is the frame that is
+    // dropped anyway), while the band as a whole takes the D-step window like any far row (unforced: right everywhere
+    // outside the box ROI +- D, which is then overwritten with the forced result).  The band lattice stays the whole
+    // band at time t / t + D on both co-owners, so nothing changes in what travels between them.  The chain of small
+    // launches stays on the caller's stream; both window launches go to a lowest-priority stream beside it.
+    const int v0 = sl->b0 + D - sl->row0, v1 = sl->b1 - D - sl->row0;
+    o0 = v0 < 0 ? 0 : v0;
+    o1 = v1 > R ? R : v1;
+    double* bl = sl->blat[sl->bcur];
+    double* bn = sl->blat[sl->bcur ^ 1];
+    const lbm_geom sg = msg_geom(D, C);
+    const int Rb = sl->bg.R, Cb = sl->xg.C, hi = sl->b1 - D;  // hi: global
+    if (sl->straddle_prev) rc = lbm_rows_copy(bl, &sl->bg, 0, sl->stash, &sg, 0, D, s);
+    else rc = lbm_rows_copy(bl, &sl->bg, 0, src, &sl->g, sl->b0 - sl->row0, D, s);
+    if (rc) return rc;
+    if (sl->straddle_next) rc = lbm_rows_copy(bl, &sl->bg, hi - sl->b0, sl->stash, &sg, 0, D, s);
+    else rc = lbm_rows_copy(bl, &sl->bg, hi - sl->b0, src, &sl->g, hi - sl->row0, D, s);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipEventRecord(sl->ev_fork, st));
+    LBM_CHECK_HIP(hipStreamWaitEvent(sl->bgst, sl->ev_fork, 0));
+    rc = lbm_bgk_stream_collide_xn(bn, bl, &sl->bg, &sl->bbc, &sl->prm, D, D, Rb - D, sl->bgst);
+    if (!rc && o0 > 0) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, 0, o0 < R ? o0 : R, sl->bgst);
+    if (!rc && o1 < R) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, o1, R, sl->bgst);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipEventRecord(sl->ev_join, sl->bgst));
+    const lbm_bc pb{LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, 0, 1.0, 1.0, 0.0, 0.0};
+    rc = box_copy(sl->box[0], sl->xg, 0, 0, bl, sl->bg, 0, sl->bc0, Rb, Cb, st);
+    int cur = 0;
+    for (int k = 1; k <= D && !rc; ++k) {  // cylinder_test.cpp:103-127 on the shrinking trapezoid
+      rc = lbm_bgk_stream_collide(sl->box[cur ^ 1], sl->box[cur], &sl->xg, &pb, &sl->prm, k, Rb - k, sl->xrho, sl->xu, s);
+      if (!rc) rc = ibm_step_window(sl->ib, 0, sl->bc0, sl->box[cur ^ 1], &sl->xg, sl->xu, sl->xrho, sl->prm.omega, sl->ga, sl->gb, st);
+      cur ^= 1;
+    }
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipStreamWaitEvent(st, sl->ev_join, 0));
+    rc = box_copy(bn, sl->bg, D, sl->bc0 + D, sl->box[cur], sl->xg, D, D, Rb - 2 * D, Cb - 2 * D, st);
+    sl->bcur ^= 1;
+    // my part of the valid rows into the slab lattice
+    if (!rc) rc = lbm_rows_copy(dst, &sl->g, o0, bn, &sl->bg, o0 + sl->row0 - sl->b0, o1 - o0, s);
+    if (rc) return rc;
+  } else if (sl->owner) {
     const int v0 = sl->b0 + D - sl->row0, v1 = sl->b1 - D - sl->row0;
     o0 = v0 < 0 ? 0 : v0;
     o1 = v1 > R ? R : v1;
@@ -320,11 +381,14 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
     if (rc) return rc;
     LBM_CHECK_HIP(hipEventRecord(sl->ev_join, sl->aux));
   }
-  // far rows: plain D-step window from the time-t lattice
-  if (o0 > 0) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, 0, o0 < R ? o0 : R, st);
-  if (!rc && o1 < R) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, o1, R, st);
-  if (rc) return rc;
-  if (sl->owner) LBM_CHECK_HIP(hipStreamWaitEvent(st, sl->ev_join, 0));
+  const bool boxed = sl->owner && sl->boxed && tuning("ibm_box", 1);
+  if (!boxed) {
+    // far rows: plain D-step window from the time-t lattice
+    if (o0 > 0) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, 0, o0 < R ? o0 : R, st);
+    if (!rc && o1 < R) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, o1, R, st);
+    if (rc) return rc;
+    if (sl->owner) LBM_CHECK_HIP(hipStreamWaitEvent(st, sl->ev_join, 0));
+  }
   // messages
   if (sl->has_prev) {
     if (sl->straddle_prev) {  // the co-owner above needs the band's lower outer rows: mine, far, now at t + D
@@ -370,6 +434,7 @@ int lbm_slab_ibm_surface_force(lbm_slab_ibm* sl, double* out2, lbm_stream_t s) {
   LBM_REQUIRE(sl && out2, "lbm_slab_ibm_surface_force: NULL argument");
   LBM_REQUIRE(sl->owner && sl->ib, "lbm_slab_ibm_surface_force: this slab does not own the boundary");
   LBM_CHECK_HIP(hipStreamSynchronize(sl->aux));
+  if (sl->bgst) LBM_CHECK_HIP(hipStreamSynchronize(sl->bgst));
   return lbm_ibm_surface_force(sl->ib, out2, s);
 }
 

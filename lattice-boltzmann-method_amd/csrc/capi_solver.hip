@@ -32,6 +32,13 @@ struct lbm_solver {
   hipStream_t side = nullptr;  // forcing chain of the immersed boundary, beside the lattice update
   hipEvent_t ev_roi = nullptr, ev_ibm = nullptr;
   double* band = nullptr;      // third lattice: odd / even steps of the forced band (solver_ibm_block)
+  // the forced BOX (solver_ibm_block): ROI +- 2 D rows and columns as a small lattice pair of its own
+  double* box[2] = {nullptr, nullptr};
+  double *box_rho = nullptr, *box_u = nullptr;
+  long long box_plane = 0;
+  int box_rows_max = 0, box_cols_max = 0;
+  hipStream_t far_st = nullptr;  // the D-step window over the whole lattice, beside the box chain; lowest priority
+  hipEvent_t ev_far_fork = nullptr, ev_far_join = nullptr;
   // pressure-periodic rows at multi-step speed (solver_pressure_block): two small lattices of 4 D rows
   // holding the rows on both sides of the virtual rows, advanced in single steps on a helper stream
   double* seam[2] = {nullptr, nullptr};
@@ -148,8 +155,15 @@ int lbm_solver_destroy(lbm_solver* sv) {
   }
   if (sv->ev_seam_fork) (void)hipEventDestroy(sv->ev_seam_fork);
   if (sv->ev_seam_join) (void)hipEventDestroy(sv->ev_seam_join);
-  for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u, sv->band, sv->seam[0], sv->seam[1]})
+  for (double* p : {sv->lat[0], sv->lat[1], sv->stage, sv->rho, sv->u, sv->band, sv->seam[0], sv->seam[1], sv->box[0], sv->box[1],
+                    sv->box_rho, sv->box_u})
     if (p) (void)hipFree(p);
+  if (sv->far_st) {
+    (void)hipStreamSynchronize(sv->far_st);
+    (void)hipStreamDestroy(sv->far_st);
+  }
+  if (sv->ev_far_fork) (void)hipEventDestroy(sv->ev_far_fork);
+  if (sv->ev_far_join) (void)hipEventDestroy(sv->ev_far_join);
   if (sv->side) {
     (void)hipStreamSynchronize(sv->side);
     (void)hipStreamDestroy(sv->side);
@@ -256,6 +270,42 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
   if (!sv->band) return 1;  // allocated by lbm_solver_attach_ibm (no allocation inside a step call)
   const double* src = sv->lat[sv->cur];
   double* dst = sv->lat[sv->cur ^ 1];
+  // The forced BOX.  The forcing reaches a node only through the ROI: columns at least 2 D away from it need the single
+  // steps as little as rows that far away do.  So the trapezoid is cut in both directions -- rows and columns ROI +- 2 D
+  // (columns widened to multiples of 8) copied into a small periodic lattice pair, D forced single steps there (what its
+  // wrap spoils is the frame that is dropped anyway), the box ROI +- D copied back -- and the D-step window runs over
+  // ALL rows from the time-t lattice, on a low-priority stream of its own beside the chain of small launches on the
+  // caller's stream.
+  // ("ibm_box" = 0: the full-width band below; also taken when the box would touch a wall column.)
+  const int bc0 = (c0 - 2 * D) / 8 * 8, bc1 = (c1 + 2 * D + 7) / 8 * 8;
+  if (sv->box[0] && sv->far_st && tuning("ibm_box", 1) && c0 - 2 * D >= 8 && bc1 <= sv->g.C - 1 && bc1 - bc0 <= sv->box_cols_max &&
+      q1 - q0 + 4 * D <= sv->box_rows_max) {
+    const int Rb = q1 - q0 + 4 * D, Cb = bc1 - bc0, br0 = q0 - 2 * D;
+    const lbm_geom bg{Rb, Cb, 0, sv->box_plane};
+    const lbm_bc pb{LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, 0, 1.0, 1.0, 0.0, 0.0};
+    const bool beside = tuning("ibm_box_overlap", 1) != 0;
+    hipStream_t far = beside ? sv->far_st : sv->st;
+    if (beside) {
+      LBM_CHECK_HIP(hipEventRecord(sv->ev_far_fork, sv->st));
+      LBM_CHECK_HIP(hipStreamWaitEvent(far, sv->ev_far_fork, 0));
+      rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, 0, R, far);
+      if (rc) return rc;
+      LBM_CHECK_HIP(hipEventRecord(sv->ev_far_join, far));
+    }
+    rc = box_copy(sv->box[0], bg, 0, 0, src, sv->g, br0, bc0, Rb, Cb, sv->st);
+    if (rc) return rc;
+    int cur = 0;
+    for (int k = 1; k <= D; ++k) {
+      rc = lbm_bgk_stream_collide(sv->box[cur ^ 1], sv->box[cur], &bg, &pb, &sv->bgk, k, Rb - k, sv->box_rho, sv->box_u, sv->st);
+      if (!rc) rc = ibm_step_window(sv->ibm, br0, bc0, sv->box[cur ^ 1], &bg, sv->box_u, sv->box_rho, sv->bgk.omega, sv->guo_a, sv->guo_b, sv->st);
+      if (rc) return rc;
+      cur ^= 1;
+    }
+    if (beside) LBM_CHECK_HIP(hipStreamWaitEvent(sv->st, sv->ev_far_join, 0));
+    else rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, 0, R, sv->st);
+    if (!rc) rc = box_copy(dst, sv->g, q0 - D, bc0 + D, sv->box[cur], bg, D, D, Rb - 2 * D, Cb - 2 * D, sv->st);
+    return rc;
+  }
   const double* in = src;
   for (int k = 1; k <= D; ++k) {
     double* out = ((D - k) % 2 == 0) ? dst : sv->band;
@@ -455,6 +505,31 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
     const size_t bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
     LBM_CHECK_HIP(hipMalloc(&sv->band, bytes));
     LBM_CHECK_HIP(hipMemsetAsync(sv->band, 0, bytes, sv->st));
+  }
+  if (ib && sv->model == LBM_MODEL_BGK) {  // the forced box of the multi-step blocks, sized for the deepest block
+    int r0, r1, c0, c1;
+    lbm_ibm_roi(ib, &r0, &r1, &c0, &c1);
+    const int Dm = 5, rows = r1 - r0 + 4 * Dm, cols = r1 > r0 ? (c1 - c0 + 4 * Dm + 16) / 8 * 8 : 0;
+    if (rows > sv->box_rows_max || cols > sv->box_cols_max) {
+      for (double** p : {&sv->box[0], &sv->box[1], &sv->box_rho, &sv->box_u}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+      }
+      sv->box_rows_max = rows;
+      sv->box_cols_max = cols;
+      sv->box_plane = (long long)rows * cols + 136;
+      const size_t n = (size_t)rows * cols;
+      LBM_CHECK_HIP(hipMalloc(&sv->box[0], (size_t)sv->box_plane * 9 * sizeof(double)));
+      LBM_CHECK_HIP(hipMalloc(&sv->box[1], (size_t)sv->box_plane * 9 * sizeof(double)));
+      LBM_CHECK_HIP(hipMalloc(&sv->box_rho, n * sizeof(double)));
+      LBM_CHECK_HIP(hipMalloc(&sv->box_u, 2 * n * sizeof(double)));
+    }
+    if (!sv->far_st) {
+      int rc = make_background_stream(&sv->far_st);
+      if (rc) return rc;
+      LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_far_fork, hipEventDisableTiming));
+      LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_far_join, hipEventDisableTiming));
+    }
   }
   sv->guo_a = guo_a;
   sv->guo_b = guo_b;

@@ -23,6 +23,20 @@ int kbc_stream_collide_x2_ref(double* p_new, const double* p_old, const lbm_geom
 int bgk_stream_collide_xn_ref(double* p_new, const double* p_old, const lbm_geom* g, const lbm_bc* bc,
                               const lbm_bgk_params* prm, int n_steps, int row_begin, int row_end, hipStream_t st);
 int bgk_collide_ref(double* p, const double* f, const lbm_geom* g, const lbm_bgk_params* prm, hipStream_t st);
+// capi_ibm.hip: lbm_ibm_step on a WINDOW of the lattice the boundary was created for -- rows [row_off, row_off + g->R),
+// columns [col_off, col_off + g->C) of it, held as a lattice of its own (p, u [2][R][C], rho [R][C] are the window's).
+// Same tables, same arithmetic; only the origin the kernels add to ROI indices moves.
+int ibm_step_window(lbm_ibm* ib, int row_off, int col_off, double* p, const lbm_geom* g, const double* u,
+                    const double* rho, double omega, double a, double b, hipStream_t st);
+// capi_core.hip: a box of n_rows x n_cols nodes, all 9 populations, between two lattices (rows in owned-row
+// indices, ghost rows allowed)
+int box_copy(double* dst, const lbm_geom& dg, int dst_row, int dst_col, const double* src, const lbm_geom& sg,
+             int src_row, int src_col, int n_rows, int n_cols, hipStream_t st);
+// capi_core.hip: a non-blocking stream of the LOWEST priority, for a grid-filling launch that runs beside a chain of
+// small dependent kernels on the caller's stream: the dispatcher then hands freed wave slots to the chain first.
+// (A stream that spares one compute unit for the chain -- hipExtStreamCreateWithCUMask -- was tried and is far slower:
+// profiles/r02_ibm_box_bench.log.)
+int make_background_stream(hipStream_t* out);
 // NumPy .npy (v1.0, little-endian f64, C order) writer shared by the snapshot objects
 int write_npy(const char* path, const double* data, const std::vector<long>& shape);
 

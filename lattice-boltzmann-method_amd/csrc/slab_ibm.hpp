@@ -26,4 +26,12 @@ struct lbm_slab_ibm {
   double* stash;         // [9][D][C]: the outer band rows the co-owner computed (state after its last block)
   hipStream_t aux;       // band chain, beside the far rows on the caller's stream
   hipEvent_t ev_fork, ev_join;
+  // the forced BOX inside the band: rows of the band x columns ROI +- 2 D (widened to multiples of 8), a small
+  // periodic lattice pair for the D forced single steps; everything else in the band takes the D-step window
+  bool boxed;
+  int bc0, bc1;          // box columns [bc0, bc1) of the lattice
+  lbm_geom xg;           // box lattice: band rows x (bc1 - bc0) columns
+  double* box[2];
+  double *xrho, *xu;
+  hipStream_t bgst;      // lowest priority: the window launches (band + far rows) beside the box chain
 };

@@ -210,6 +210,6 @@ if __name__ == "__main__":
     if "cg" in which:
         bench_cg(8192, 2048)
     if "ibm" in which:
-        bench_cylinder(16384 // 8, 4096)   # one 8-GPU slab of config 5
-        bench_cylinder(4096, 4096)
-        bench_cylinder(16384, 4096)      # config 5 whole on one GPU
+        # 2048: one 8-GPU slab of config 5; 16384: config 5 whole on one GPU
+        for rows in os.environ.get("LBM_IBM_SIZES", "2048,4096,16384").split(","):
+            bench_cylinder(int(rows), 4096)

@@ -925,7 +925,7 @@ def test_native_ring_one_exchange_per_several_launches(lib, oracle, walls, perio
         torch.cuda.synchronize()
         assert torch.equal(lat[cur][:, G:G + R], a)
     finally:
-        lib.set_tuning(b"ring_period", 0)
+        lib.set_tuning(b"ring_period", -1)
         lib.ring_destroy(ring)
 
 
