@@ -340,9 +340,11 @@ int lbm_ibm_force(lbm_ibm* ib, const double* u, const double* rho, double* F_out
  * p[q][roi] += (1 - omega/2) w_q [ (a + b c_q.u)(c_q.F) - a u.F ]  with the UNcorrected u */
 int lbm_ibm_add_source(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, double omega,
                        double a, double b, lbm_stream_t s);
-/* lbm_ibm_force + lbm_ibm_add_source of one time step as ONE launch of one workgroup (the 2 (m_max-1)
- * + 2 small dependent launches are a latency chain otherwise); bit-identical results.  What the
- * solver context and the slab ring call. */
+/* lbm_ibm_force + lbm_ibm_add_source of one time step as TWO launches -- all forcing iterations in one
+ * workgroup with its working set in LDS, then the source term on the touched nodes -- instead of
+ * 2 (m_max-1) + 2 small dependent ones; bit-identical results.  What the solver context and the slab
+ * engines call.  Tuning: "ibm_step_opt" 0 = the round-1 table layout, "ibm_step_split" 0 = source term
+ * inside the workgroup, "ibm_step_chain" 1 = the launch chain. */
 int lbm_ibm_step(lbm_ibm* ib, double* p, const lbm_geom* g, const double* u, const double* rho,
                  double omega, double a, double b, lbm_stream_t s);
 /* F_s = sum over the ROI of F (drag, lift), cylinder_test.cpp:112; host out[2], synchronises */
@@ -602,7 +604,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * 1: they may use the reassociated model too, 1e-10 instead of bitwise on the cylinder preset), "ibm_depth" (steps lbm_solver_step advances per block on a BGK lattice with an immersed boundary: forced
  * band around the ROI in single steps, rows at least that far away through the multi-step window; default 5,
  * 1 = one step per launch everywhere; same bits), "pressure_depth" (steps per block on lattices with pressure-periodic rows: the 2 D rows on either side of the virtual rows in single steps on a small periodic
- * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ring_period" (1: lbm_ring_bgk_step exchanges on every launch even when the slabs carry m x n_steps ghost rows; default 0 = one exchange per m launches), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
+ * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ibm_box" (0: the forced single steps of an immersed-boundary block run over full-width band rows instead of a box of ROI +- 2 D rows and columns), "ibm_box_overlap" (0: box chain and window launch one after the other on the caller's stream), "bg_priority" (0: the background stream of those window launches gets default instead of lowest priority), "ring_period" (1: lbm_ring_bgk_step exchanges on every launch even when the slabs carry m x n_steps ghost rows; default 0 = one exchange per m launches), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
  * forcing workgroup is resident; 0: off), "sw_split" (1 [default]: wall-bounded
  * multi-step launches run their wall-free interior through the plain instantiation and only the frame of
  * outermost strips / rows next to a wall row through the wall-carrying one, on a helper stream; 0: one
