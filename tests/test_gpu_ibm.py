@@ -243,6 +243,41 @@ def test_forced_band_blocks_equal_single_steps(lib, oracle, cx_frac):
         assert np.allclose(Fs, Fso, rtol=1e-11, atol=1e-16)
 
 
+@pytest.mark.parametrize("tune,cy_frac", [
+    ({"ibm_box": 0}, 0.55),                          # full-width band (round 2, first half)
+    ({"ibm_box": 1, "ibm_box_overlap": 0}, 0.55),    # forced box, window launch behind the chain on one stream
+    ({"ibm_box": 1, "ibm_step_chain": 1}, 0.55),     # box; forcing as the 10-launch chain
+    ({"ibm_box": 1, "ibm_step_opt": 0, "ibm_step_split": 0}, 0.55),  # box; the one-workgroup kernel of round 1
+    ({"ibm_box": 1, "bg_priority": 0}, 0.55),
+    ({"ibm_box": 1}, 0.12),                          # box would touch the wall columns: the band takes over
+    ({"ibm_box": 1}, 0.87),
+])
+def test_forced_box_variants_equal_the_oracle(lib, oracle, tune, cy_frac):
+    """The forced BOX of an immersed-boundary block (rows and columns ROI +- 2 D on a small lattice of its own,
+    D-step window over all rows beside it) and every switch around it: same bits as the oracle after 16 steps
+    (1 + three 5-step blocks), same surface force; the blocks really ran (lbm_solver_block_launches)."""
+    X, Y, omega, u_in, radius = 176, 200, 1.0 / 0.55, 0.05, 9.0
+    x, y = circle(X * 0.45 + 0.3, Y * cy_frac - 0.4, radius)
+    u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
+    f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
+    fo, uo, rhoo, Fso = oracle.cylinder_steps(x, y, f0, omega, u_in, 16)
+    try:
+        for k, v in tune.items():
+            lib.set_tuning(k.encode(), v)
+        sv, ib = cylinder_solver(lib, X, Y, omega, u_in, x, y)
+        sv.set_f(f0)
+        sv.step(16, record_moments=False)
+        f, Fs = sv.get_f(), ib.surface_force()
+        blocks = int(lib.raw.lbm_solver_block_launches(sv.h))
+        sv.close(); ib.close()
+    finally:
+        for k in tune:
+            lib.set_tuning(k.encode(), -1)
+    assert blocks == 3, blocks
+    assert bits_equal(f, fo), ulp_diff(f, fo)
+    assert np.allclose(Fs, Fso, rtol=1e-11, atol=1e-16)
+
+
 def test_cylinder_with_reassociated_delta_form(lib, oracle):
     """Opt-in (tuning bgk_fast_delta = 1): the cylinder preset's delta-form collision through the
     reassociated model -- not bitwise any more, 1e-10 relative on f after 13 steps (north star: 1e-8)."""
