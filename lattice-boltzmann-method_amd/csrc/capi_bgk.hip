@@ -200,3 +200,5 @@ int lbm::bgk_collide_ref(double* p, const double* f, const lbm_geom* g, const lb
   const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
   return launch_collide_only("bgk_collide_ref", p, f, g, nullptr, m, nullptr, nullptr, st);
 }
+
+bool lbm::bgk_uses_fast_model(const lbm_bgk_params* prm, const lbm_bc* bc) { return prm && use_fast_bgk(prm, bc); }

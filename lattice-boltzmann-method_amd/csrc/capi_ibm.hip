@@ -164,15 +164,23 @@ __global__ __launch_bounds__(256) void k_ibm_add_source_touched(IbmDev d, double
 // OPT = 1 (default; "ibm_step_opt" = 0 selects the form of round 1, same bits): taps and (marker, weight) pairs are read
 // from the lane-major tables (IbmDev::tap_k ... ell_w), pairs 4 at a time; all sums keep their order.  The launch is one workgroup deep: its time IS its chain of
 // latencies (82 us -> see profiles/r02_ibm_force.txt).
-template <int OPT, int MAXOWN>
-__global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const double* __restrict__ u,
-                                                   const double* __restrict__ rho,
-                                                   double* __restrict__ F_sum, double* __restrict__ p,
-                                                   Geom g, double omega, double a, double b,
-                                                   int with_source, int* flag = nullptr, int seq = 0) {
-  // resident: tell the gate on the lattice stream (k_ibm_gate) that the rest of the step may start
-  if (flag && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  extern __shared__ double lds[];
+// COH: accesses that are coherent across the compute units of the device without any cache-wide maintenance (agent-scope
+// relaxed atomics = sc1 loads / stores): for data that workgroups on different XCDs hand to each other inside one launch
+template <bool COH>
+__device__ __forceinline__ double ld_d(const double* p) {
+  return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool COH>
+__device__ __forceinline__ void st_d(double* p, double v) {
+  if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
+
+template <int OPT, int MAXOWN, bool COH = false>
+__device__ __forceinline__ void ibm_force_wg(const IbmDev& d, int m_max, const double* u,
+                                             const double* rho, double* F_sum,
+                                             double* __restrict__ p, const Geom& g, double omega, double a, double b,
+                                             int with_source, double* lds) {
   const int nt = d.n_touched, nm = d.n_markers, n = d.RR * d.RC;
   double* s_ux = lds;            // [nt]
   double* s_uy = lds + nt;       // [nt]
@@ -193,9 +201,9 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
     if (t < nt) {
       const int i = d.touched[t];
       const long s = (long)(d.r0 + i / d.RC) * d.Y + (d.c0 + i % d.RC);
-      s_ux[t] = u[s];
-      s_uy[t] = u[N + s];
-      s_rho[t] = rho[s];
+      s_ux[t] = ld_d<COH>(u + s);
+      s_uy[t] = ld_d<COH>(u + N + s);
+      s_rho[t] = ld_d<COH>(rho + s);
       if (OPT) cnt[k] = d.ell_cnt[t];
     }
   }
@@ -277,8 +285,8 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
     const int t = threadIdx.x + k * 1024;
     if (t >= nt) continue;
     const int i = d.touched[t];
-    F_sum[i] = Fx[k];
-    F_sum[n + i] = Fy[k];
+    st_d<COH>(F_sum + i, Fx[k]);
+    st_d<COH>(F_sum + n + i, Fy[k]);
     if (!with_source) continue;
     const int r = d.r0 + i / d.RC, c = d.c0 + i % d.RC;
     const long s = (long)r * d.Y + c;
@@ -291,6 +299,128 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
       const double cF = Fx[k] * (double)icx(q) + Fy[k] * (double)icy(q);
       p[q * g.plane + o] += ((1 - 0.5 * omega) * ((a + b * cu) * cF - a * uF) * wq(q));
     }
+  }
+}
+
+template <int OPT, int MAXOWN>
+__global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const double* __restrict__ u,
+                                                   const double* __restrict__ rho,
+                                                   double* __restrict__ F_sum, double* __restrict__ p,
+                                                   Geom g, double omega, double a, double b,
+                                                   int with_source, int* flag = nullptr, int seq = 0) {
+  // resident: tell the gate on the lattice stream (k_ibm_gate) that the rest of the step may start
+  if (flag && threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  extern __shared__ double lds[];
+  ibm_force_wg<OPT, MAXOWN>(d, m_max, u, rho, F_sum, p, g, omega, a, b, with_source, lds);
+}
+
+// ---- the whole chain of a forced box in ONE launch ---------------------------------------------------------------
+// D x (single BGK step on the box lattice, forcing, source term) for a block of an immersed-boundary lattice, as one
+// kernel of a few workgroups that hold their compute units for the whole block: beside a grid-filling window launch
+// the 3 D small dependent launches of the chain each wait for wave slots and then share their SIMDs with its waves
+// (2-3 x slower, profiles/r02_ibm_block_trace_*.txt).  Every workgroup asks for the forcing's LDS, so each sits
+// alone on a compute unit.  Phases are separated by a barrier over the grid: arrival counter + generation word,
+// agent-scope release before / acquire after (the workgroups sit on different XCDs, whose L2s are not coherent for
+// plain stores), and a BOUNDED spin -- if the grid is ever not co-resident the kernel gives up, flags it
+// (lbm_ibm_surface_force and lbm_ibm_chain_status report it) and ends; nothing can hang.
+// Per node the arithmetic is that of k_stream_collide_v2 / k_ibm_step / k_ibm_add_source_touched: same bits.
+struct ChainSync {
+  unsigned* cnt;   // arrivals at the current barrier
+  unsigned* gen;   // barriers completed so far (monotonic over launches; the host passes the value at launch)
+  int* abort;      // set when a spin ran out of budget
+};
+__device__ __forceinline__ bool chain_barrier(const ChainSync& sy, unsigned nwg, unsigned& my_gen) {
+  // everything the workgroups hand to each other goes through coherent accesses (ld_d / st_d<true>): the barrier only
+  // has to order them -- this wave's memory operations complete (workgroup-scope fence = s_waitcnt), the workgroup
+  // meets, one lane announces it.  No agent-scope fence: that would write back and invalidate the XCD's whole L2 under
+  // the window launch running beside (measured: chain 155 us per step, window launch 520 instead of 380 us).
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  __syncthreads();
+  __shared__ int s_ok;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned prev = __hip_atomic_fetch_add(sy.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == nwg - 1) {
+      __hip_atomic_store(sy.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the reset is performed before the release of the others
+      __hip_atomic_store(sy.gen, my_gen + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      long budget = 400000;  // x (sleep + one memory round trip): some 0.1-0.4 s
+      while (__hip_atomic_load(sy.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen && --budget > 0 &&
+             __hip_atomic_load(sy.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __builtin_amdgcn_s_sleep(1);
+      if (__hip_atomic_load(sy.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen) {
+        __hip_atomic_store(sy.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+      }
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  const bool ok = s_ok != 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  ++my_gen;
+  return ok;
+}
+
+template <class Model, int MAXOWN>
+__global__ __launch_bounds__(1024) void k_ibm_box_chain(IbmDev d, int m_max, double* bx0, double* bx1, Geom g, Model m,
+                                                        int D, double* xrho, double* xu,
+                                                        double* F_sum, double omega, double a, double b,
+                                                        ChainSync sy, unsigned gen0, int* flag, int seq) {
+  extern __shared__ double lds[];
+  const unsigned nwg = gridDim.x;
+  unsigned my_gen = gen0;
+  if (!chain_barrier(sy, nwg, my_gen)) return;  // every workgroup holds its compute unit from here on
+  if (blockIdx.x == 0 && threadIdx.x == 0 && flag) __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int Rb = g.R, Cb = g.C;
+  const long n = (long)Rb * Cb;
+  double* in = bx0;
+  double* out = bx1;
+  for (int k = 1; k <= D; ++k) {
+    // single step on rows [k, Rb - k): cylinder_test.cpp:103-109 on the shrinking trapezoid
+    const long items = (long)(Rb - 2 * k) * Cb;
+    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < items; i += (long)nwg * 1024) {
+      const int r = k + (int)(i / Cb), c = (int)(i % Cb);
+      const long rows[3] = {g.at(wrap_row(g, r + 1), 0), g.at(r, 0), g.at(wrap_row(g, r - 1), 0)};
+      const int cols[3] = {wrap_col(g, c + 1), c, wrap_col(g, c - 1)};
+      double f[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = ld_d<true>(in + q * g.plane + rows[icx(q) + 1] + cols[icy(q) + 1]);
+      double rho, ux, uy;
+      m.collide(f, rho, ux, uy);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) st_d<true>(out + q * g.plane + rows[1] + c, f[q]);
+      const long o = (long)r * Cb + c;
+      st_d<true>(xrho + o, rho);
+      st_d<true>(xu + o, ux);
+      st_d<true>(xu + n + o, uy);
+    }
+    if (!chain_barrier(sy, nwg, my_gen)) return;
+    if (blockIdx.x == 0) ibm_force_wg<1, MAXOWN, true>(d, m_max, xu, xrho, F_sum, out, g, omega, a, b, 0, lds);
+    if (!chain_barrier(sy, nwg, my_gen)) return;
+    {  // source term on the touched nodes (== k_ibm_add_source_touched)
+      const int nroi = d.RR * d.RC;
+      for (int t = blockIdx.x * 1024 + threadIdx.x; t < d.n_touched; t += nwg * 1024) {
+        const int i = d.touched[t];
+        const int r = d.r0 + i / d.RC, c = d.c0 + i % d.RC;
+        const long s = (long)r * d.Y + c, N = (long)d.X * d.Y;
+        const double ux = ld_d<true>(xu + s), uy = ld_d<true>(xu + N + s), Fx = ld_d<true>(F_sum + i), Fy = ld_d<true>(F_sum + nroi + i);
+        const double uF = ux * Fx + uy * Fy;
+        const long o = g.at(r, c);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          const double cu = ux * (double)icx(q) + uy * (double)icy(q);
+          const double cF = Fx * (double)icx(q) + Fy * (double)icy(q);
+          double* pq = out + q * g.plane + o;
+          st_d<true>(pq, ld_d<true>(pq) + ((1 - 0.5 * omega) * ((a + b * cu) * cF - a * uF) * wq(q)));
+        }
+      }
+    }
+    if (k < D && !chain_barrier(sy, nwg, my_gen)) return;
+    double* t_ = in;
+    in = out;
+    out = t_;
   }
 }
 
@@ -342,6 +472,8 @@ struct lbm_ibm {
   unsigned lds_opt_in = 0;  // bit per k_ibm_step instantiation that has its dynamic-LDS limit raised
   void* dev_blob;                  // all constant device arrays in one allocation
   void* dev_blob2;                 // their lane-major copies (k_ibm_step)
+  unsigned* chain_sync = nullptr;  // device: {arrivals, generation, abort} of k_ibm_box_chain's grid barrier
+  unsigned chain_gen = 0;          // host: barriers passed by all launches so far
   double *u_roi, *rho_roi, *F_sum, *fj, *out2;  // device work arrays
 };
 
@@ -484,6 +616,8 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
   if (e == hipSuccess) e = hipMalloc(&ib->out2, 16);
   if (e == hipSuccess) e = hipMalloc(&ib->flag, sizeof(int));
   if (e == hipSuccess) e = hipMemset(ib->flag, 0, sizeof(int));
+  if (e == hipSuccess) e = hipMalloc(&ib->chain_sync, 4 * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(ib->chain_sync, 0, 4 * sizeof(unsigned));
   if (e != hipSuccess) {
     set_error("lbm_ibm_create: HIP allocation/copy failed: %s", hipGetErrorString(e));
     lbm_ibm_destroy(ib);
@@ -514,7 +648,7 @@ int lbm_ibm_create_slab(lbm_ibm** out, const double* x, const double* y, int n_m
 int lbm_ibm_destroy(lbm_ibm* ib) {
   if (!ib) return LBM_OK;
   for (void* p : {ib->dev_blob, ib->dev_blob2, (void*)ib->u_roi, (void*)ib->rho_roi, (void*)ib->F_sum,
-                  (void*)ib->fj, (void*)ib->out2, (void*)ib->flag})
+                  (void*)ib->fj, (void*)ib->out2, (void*)ib->flag, (void*)ib->chain_sync})
     if (p) (void)hipFree(p);
   delete ib;
   return LBM_OK;
@@ -635,6 +769,59 @@ int ibm_step_window(lbm_ibm* ib, int row_off, int col_off, double* p, const lbm_
   ib->lds_opt_in = w.lds_opt_in;
   return rc;
 }
+// D forced single steps of a box lattice pair in one launch (k_ibm_box_chain); *cur: index of the lattice holding the
+// state (in: time t, out: time t + D).  Returns 1 when the boundary does not qualify (too many touched nodes for the
+// one-workgroup forcing, or switched off): the caller runs the launch chain instead.
+int ibm_box_chain(lbm_ibm* ib, int row_off, int col_off, double* const box[2], int* cur, const lbm_geom* g,
+                  const lbm_bgk_params* prm, bool fast_model, int D, double* xrho, double* xu, double a, double b,
+                  hipStream_t st) {
+  LBM_REQUIRE(ib && box && cur && g && prm, "ibm_box_chain: NULL argument");
+  const size_t lds = ((size_t)3 * ib->d.n_touched + 2 * (size_t)ib->d.n_markers) * sizeof(double);
+  const int nwg = tuning("ibm_chain_wgs", 16);
+  if (nwg < 2 || nwg > 64 || ib->d.n_touched > 6144 || lds > 150 * 1024 || g->ghost != 0) return 1;
+  LBM_REQUIRE(ib->d.r0 - row_off >= 1 && ib->d.c0 - col_off >= 1 && ib->r1 - row_off <= g->R - 1 && ib->c1 - col_off <= g->C - 1,
+              "ibm_box_chain: ROI outside the window");
+  IbmDev d = ib->d;
+  d.r0 -= row_off;
+  d.c0 -= col_off;
+  d.X = g->R;
+  d.Y = g->C;
+  ChainSync sy{ib->chain_sync, ib->chain_sync + 1, reinterpret_cast<int*>(ib->chain_sync + 2)};
+  const unsigned gen0 = ib->chain_gen;
+  ib->chain_gen += 3u * (unsigned)D;  // 1 at entry + 3 per step - 1 (none behind the last source term)
+  ++ib->seq;
+  ib->gate_ok = true;
+  const Geom gg = make_geom(*g);
+  const int own = ib->d.n_touched <= 4096 ? 4 : 6;
+  auto go = [&](auto kern, auto model) -> int {
+    LBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    // (at least 100 KB each: one workgroup per compute unit, whatever the forcing itself needs)
+    const size_t want = lds > 100 * 1024 ? lds : 100 * 1024;
+    LBM_KLAUNCH(kern, dim3(nwg), dim3(1024), want, st, d, ib->m_max, box[*cur], box[*cur ^ 1], gg, model, D, xrho, xu, ib->F_sum,
+                prm->omega, a, b, sy, gen0, ib->flag, ib->seq);
+    LBM_CHECK_LAUNCH();
+    return LBM_OK;
+  };
+  int rc;
+  if (fast_model) {
+    const BgkFastModel m(prm->omega);
+    rc = own == 4 ? go(&k_ibm_box_chain<BgkFastModel, 4>, m) : go(&k_ibm_box_chain<BgkFastModel, 6>, m);
+  } else {
+    const BgkModel m{prm->omega, prm->incompressible, prm->delta_form, prm->force_mode, prm->force_r, prm->force_c, prm->guo_a, prm->guo_b};
+    rc = own == 4 ? go(&k_ibm_box_chain<BgkModel, 4>, m) : go(&k_ibm_box_chain<BgkModel, 6>, m);
+  }
+  if (rc) return rc;
+  if (D % 2) *cur ^= 1;
+  return LBM_OK;
+}
+// 0: no launch of k_ibm_box_chain ever gave up at its grid barrier (synchronises the device word read)
+int ibm_chain_status(lbm_ibm* ib, hipStream_t st) {
+  int flag = 0;
+  LBM_CHECK_HIP(hipMemcpyAsync(&flag, ib->chain_sync + 2, sizeof flag, hipMemcpyDeviceToHost, st));
+  LBM_CHECK_HIP(hipStreamSynchronize(st));
+  LBM_REQUIRE(flag == 0, "immersed boundary: a forced-box launch gave up at its grid barrier (its workgroups were not co-resident); results since then are invalid");
+  return LBM_OK;
+}
 int ibm_gate(lbm_ibm* ib, hipStream_t st) {
   if (!ib || !ib->gate_ok || tuning("ibm_gate", 1) == 0) return LBM_OK;
   LBM_KLAUNCH(k_ibm_gate, dim3(1), dim3(64), 0, st, ib->flag, ib->seq, 4000);  // <= ~4 ms, then gives up
@@ -646,6 +833,10 @@ extern "C" {
 
 int lbm_ibm_surface_force(lbm_ibm* ib, double* out2, lbm_stream_t s) {
   LBM_REQUIRE(ib && out2, "lbm_ibm_surface_force: NULL argument");
+  if (ib->chain_gen) {
+    const int rc = ibm_chain_status(ib, as_stream(s));
+    if (rc) return rc;
+  }
   LBM_KLAUNCH(k_ibm_sum, dim3(1), dim3(256), 0, as_stream(s), ib->d.RR * ib->d.RC, ib->F_sum, ib->out2);
   LBM_CHECK_LAUNCH();
   LBM_CHECK_HIP(hipMemcpyAsync(out2, ib->out2, 16, hipMemcpyDeviceToHost, as_stream(s)));

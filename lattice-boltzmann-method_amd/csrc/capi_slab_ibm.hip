@@ -330,16 +330,25 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
     else rc = lbm_rows_copy(bl, &sl->bg, hi - sl->b0, src, &sl->g, hi - sl->row0, D, s);
     if (rc) return rc;
     LBM_CHECK_HIP(hipEventRecord(sl->ev_fork, st));
+    const lbm_bc pb{LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, 0, 1.0, 1.0, 0.0, 0.0};
+    rc = box_copy(sl->box[0], sl->xg, 0, 0, bl, sl->bg, 0, sl->bc0, Rb, Cb, st);
+    if (rc) return rc;
+    int cur = 0;
+    // "ibm_chain_kernel" = 1 (opt-in, level with the default): the chain as ONE launch on compute units of its own
+    // (lbm::ibm_box_chain), the window launches held back until its workgroups are resident
+    rc = tuning("ibm_chain_kernel", 0) ? ibm_box_chain(sl->ib, 0, sl->bc0, sl->box, &cur, &sl->xg, &sl->prm, bgk_uses_fast_model(&sl->prm, &pb), D,
+                                                       sl->xrho, sl->xu, sl->ga, sl->gb, st)
+                                       : 1;
+    if (rc < 0) return rc;
+    const bool one_launch = rc == 0;
     LBM_CHECK_HIP(hipStreamWaitEvent(sl->bgst, sl->ev_fork, 0));
-    rc = lbm_bgk_stream_collide_xn(bn, bl, &sl->bg, &sl->bbc, &sl->prm, D, D, Rb - D, sl->bgst);
+    rc = one_launch ? ibm_gate(sl->ib, sl->bgst) : LBM_OK;
+    if (!rc) rc = lbm_bgk_stream_collide_xn(bn, bl, &sl->bg, &sl->bbc, &sl->prm, D, D, Rb - D, sl->bgst);
     if (!rc && o0 > 0) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, 0, o0 < R ? o0 : R, sl->bgst);
     if (!rc && o1 < R) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, o1, R, sl->bgst);
     if (rc) return rc;
     LBM_CHECK_HIP(hipEventRecord(sl->ev_join, sl->bgst));
-    const lbm_bc pb{LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, 0, 1.0, 1.0, 0.0, 0.0};
-    rc = box_copy(sl->box[0], sl->xg, 0, 0, bl, sl->bg, 0, sl->bc0, Rb, Cb, st);
-    int cur = 0;
-    for (int k = 1; k <= D && !rc; ++k) {  // cylinder_test.cpp:103-127 on the shrinking trapezoid
+    for (int k = 1; k <= D && !one_launch && !rc; ++k) {  // cylinder_test.cpp:103-127 on the shrinking trapezoid
       rc = lbm_bgk_stream_collide(sl->box[cur ^ 1], sl->box[cur], &sl->xg, &pb, &sl->prm, k, Rb - k, sl->xrho, sl->xu, s);
       if (!rc) rc = ibm_step_window(sl->ib, 0, sl->bc0, sl->box[cur ^ 1], &sl->xg, sl->xu, sl->xrho, sl->prm.omega, sl->ga, sl->gb, st);
       cur ^= 1;

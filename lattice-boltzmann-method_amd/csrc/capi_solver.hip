@@ -285,17 +285,28 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
     const lbm_bc pb{LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, 0, 1.0, 1.0, 0.0, 0.0};
     const bool beside = tuning("ibm_box_overlap", 1) != 0;
     hipStream_t far = beside ? sv->far_st : sv->st;
-    if (beside) {
-      LBM_CHECK_HIP(hipEventRecord(sv->ev_far_fork, sv->st));
-      LBM_CHECK_HIP(hipStreamWaitEvent(far, sv->ev_far_fork, 0));
-      rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, 0, R, far);
-      if (rc) return rc;
-      LBM_CHECK_HIP(hipEventRecord(sv->ev_far_join, far));
-    }
+    if (beside) LBM_CHECK_HIP(hipEventRecord(sv->ev_far_fork, sv->st));
     rc = box_copy(sv->box[0], bg, 0, 0, src, sv->g, br0, bc0, Rb, Cb, sv->st);
     if (rc) return rc;
     int cur = 0;
-    for (int k = 1; k <= D; ++k) {
+    // "ibm_chain_kernel" = 1 (opt-in): the chain as ONE launch of a few workgroups on compute units of their own, the
+    // window launch held back until they are resident.  Bit-identical; measured level with the 3 D small launches
+    // (73 / 87 / 118 k against 77 / 98 / 121 k MLUPS at 2048 / 4096 / 16384 rows): what it gains in isolation it loses to
+    // coherent (L2-bypassing) accesses and 3 D grid barriers -- DESIGN 5.3
+    rc = tuning("ibm_chain_kernel", 0) ? ibm_box_chain(sv->ibm, br0, bc0, sv->box, &cur, &bg, &sv->bgk, bgk_uses_fast_model(&sv->bgk, &pb), D,
+                                                       sv->box_rho, sv->box_u, sv->guo_a, sv->guo_b, sv->st)
+                                       : 1;
+    if (rc < 0) return rc;
+    const bool one_launch = rc == 0;
+    if (beside) {
+      LBM_CHECK_HIP(hipStreamWaitEvent(far, sv->ev_far_fork, 0));
+      if (one_launch) rc = ibm_gate(sv->ibm, far);
+      else rc = LBM_OK;
+      if (!rc) rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, 0, R, far);
+      if (rc) return rc;
+      LBM_CHECK_HIP(hipEventRecord(sv->ev_far_join, far));
+    }
+    for (int k = 1; k <= D && !one_launch; ++k) {
       rc = lbm_bgk_stream_collide(sv->box[cur ^ 1], sv->box[cur], &bg, &pb, &sv->bgk, k, Rb - k, sv->box_rho, sv->box_u, sv->st);
       if (!rc) rc = ibm_step_window(sv->ibm, br0, bc0, sv->box[cur ^ 1], &bg, sv->box_u, sv->box_rho, sv->bgk.omega, sv->guo_a, sv->guo_b, sv->st);
       if (rc) return rc;

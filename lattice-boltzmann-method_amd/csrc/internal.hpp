@@ -28,6 +28,13 @@ int bgk_collide_ref(double* p, const double* f, const lbm_geom* g, const lbm_bgk
 // Same tables, same arithmetic; only the origin the kernels add to ROI indices moves.
 int ibm_step_window(lbm_ibm* ib, int row_off, int col_off, double* p, const lbm_geom* g, const double* u,
                     const double* rho, double omega, double a, double b, hipStream_t st);
+// capi_ibm.hip: the D forced single steps of a box lattice pair (box step + forcing + source term, D times) as ONE
+// launch of a few workgroups on compute units of their own; *cur flips when D is odd.  1 = not applicable.
+int ibm_box_chain(lbm_ibm* ib, int row_off, int col_off, double* const box[2], int* cur, const lbm_geom* g,
+                  const lbm_bgk_params* prm, bool fast_model, int D, double* xrho, double* xu, double a, double b,
+                  hipStream_t st);
+// capi_bgk.hip: the model lbm_bgk_stream_collide picks for these parameters (reassociated or reference order)
+bool bgk_uses_fast_model(const lbm_bgk_params* prm, const lbm_bc* bc);
 // capi_core.hip: a box of n_rows x n_cols nodes, all 9 populations, between two lattices (rows in owned-row
 // indices, ghost rows allowed)
 int box_copy(double* dst, const lbm_geom& dg, int dst_row, int dst_col, const double* src, const lbm_geom& sg,
