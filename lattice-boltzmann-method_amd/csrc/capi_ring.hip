@@ -88,6 +88,7 @@ struct lbm_ring {
   hipEvent_t main_done, edge_done, aux_done;
   double *send_next, *send_prev, *recv_prev, *recv_next;
   // lbm_ring_profile(1): timed events around the three phases of the last launch-step
+  int closed;                    // periodic ring (every rank has both neighbours), not a chain with two ends
   int phase;                     // launches since the last exchange (ghost = m x steps: one exchange per m launches)
   int profile;
   hipEvent_t t_edge0, t_edge1, t_xchg1, t_main0, t_main1;
@@ -121,6 +122,7 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
   rg->nranks = nranks;
   rg->next = (periodic || rank < nranks - 1) ? (rank + 1) % nranks : -1;
   rg->prev = (periodic || rank > 0) ? (rank + nranks - 1) % nranks : -1;
+  rg->closed = periodic ? 1 : 0;
   rg->g = *slab;
   rg->msg = (size_t)lbm_halo_rows(slab->ghost) * slab->C;
   ncclUniqueId id;
@@ -344,7 +346,8 @@ static int ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm
   // the later launches of the period still read (n_steps fewer per side each time; 2 x 5 extra rows in 1024 at m = 2),
   // and the last one is the overlapped launch-step below with all m x n_steps ghost rows in the message.  Every rank
   // takes the same branch: the decision depends on the ring's shape and on the call sequence only.
-  const int m = (may_skip && n_steps > 1 && rg->prev >= 0 && rg->next >= 0 && tuning("ring_period", 0) != 1) ? G / n_steps : 1;
+  // (rg->closed, not "this rank has both neighbours": the middle ranks of a CHAIN have them too, its end ranks do not)
+  const int m = (may_skip && n_steps > 1 && rg->closed && tuning("ring_period", 0) != 1) ? G / n_steps : 1;
   if (m > 1) {
     const int left = m - 1 - rg->phase;  // launches after this one before the next exchange
     if (left > 0) {
