@@ -89,7 +89,7 @@ struct lbm_ring {
   double *send_next, *send_prev, *recv_prev, *recv_next;
   // lbm_ring_profile(1): timed events around the three phases of the last launch-step
   int closed;                    // periodic ring (every rank has both neighbours), not a chain with two ends
-  int phase;                     // launches since the last exchange (ghost = m x steps: one exchange per m launches)
+  int valid;                     // ghost rows per side known to be current (set by an exchange, used up by launches without one)
   int profile;
   hipEvent_t t_edge0, t_edge1, t_xchg1, t_main0, t_main1;
 };
@@ -180,7 +180,7 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   // two lattices = the two colours; full = complete ghost rows (multi-step launches with walls)
   const int G = lattice2 ? LBM_HALO_TWO_PHASE : (full ? LBM_HALO_FULL(rg->g.ghost) : rg->g.ghost);
   const size_t msg = (size_t)lbm_halo_rows(G) * rg->g.C;
-  rg->phase = 0;  // every ghost row is current again
+  rg->valid = lattice2 ? 3 : rg->g.ghost;  // these ghost rows are current again
   if (as_stream(after) != rg->edge) {
     LBM_CHECK_HIP(hipEventRecord(rg->main_done, as_stream(after)));
     LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
@@ -345,19 +345,18 @@ static int ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm
   // m - 1 launches in between run as ONE plain launch on the caller's stream over the owned rows plus the ghost rows
   // the later launches of the period still read (n_steps fewer per side each time; 2 x 5 extra rows in 1024 at m = 2),
   // and the last one is the overlapped launch-step below with all m x n_steps ghost rows in the message.  Every rank
-  // takes the same branch: the decision depends on the ring's shape and on the call sequence only.
-  // (rg->closed, not "this rank has both neighbours": the middle ranks of a CHAIN have them too, its end ranks do not)
-  const int m = (may_skip && n_steps > 1 && rg->closed && tuning("ring_period", 0) != 1) ? G / n_steps : 1;
-  if (m > 1) {
-    const int left = m - 1 - rg->phase;  // launches after this one before the next exchange
-    if (left > 0) {
-      lbm_geom g2 = rg->g;
-      g2.plane_stride = make_geom(rg->g).plane;
-      g2.R = R + 2 * left * n_steps;
-      g2.ghost = G - left * n_steps;
-      ++rg->phase;
-      return lbm_bgk_stream_collide_xn(dst, src, &g2, &b, prm, n_steps, 0, g2.R, main_s);
-    }
+  // takes the same branch: the decision depends on the ring's shape (rg->closed -- not "this rank has both neighbours":
+  // the middle ranks of a CHAIN have them too, its end ranks do not) and on the call sequence (rg->valid: ghost rows
+  // current after the last exchange minus what launches without one have used up; depths may vary from call to call).
+  if (may_skip && n_steps > 1 && rg->closed && tuning("ring_period", 0) != 1 && rg->valid >= 2 * n_steps) {
+    // enough current ghost rows for this launch AND a later one: no exchange now.  e rows per side stay current
+    const int e = rg->valid - n_steps;
+    lbm_geom g2 = rg->g;
+    g2.plane_stride = make_geom(rg->g).plane;
+    g2.R = R + 2 * e;
+    g2.ghost = G - e;
+    rg->valid = e;
+    return lbm_bgk_stream_collide_xn(dst, src, &g2, &b, prm, n_steps, 0, g2.R, main_s);
   }
   // walls + several steps per launch: the NEXT launch reads complete ghost rows
   const bool full = n_steps > 1 && (bc_is_wall(b.row_lo) || bc_is_wall(b.row_hi) || bc_is_wall(b.col_lo) || bc_is_wall(b.col_hi));

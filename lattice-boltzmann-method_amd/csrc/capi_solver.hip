@@ -520,14 +520,21 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
   if (ib && sv->model == LBM_MODEL_BGK) {  // the forced box of the multi-step blocks, sized for the deepest block
     int r0, r1, c0, c1;
     lbm_ibm_roi(ib, &r0, &r1, &c0, &c1);
-    const int Dm = 5, rows = r1 - r0 + 4 * Dm, cols = r1 > r0 ? (c1 - c0 + 4 * Dm + 16) / 8 * 8 : 0;
+    const int Dm = 5;
+    int rows = r1 - r0 + 4 * Dm, cols = (c1 - c0 + 4 * Dm + 16) / 8 * 8;
     if (rows > sv->box_rows_max || cols > sv->box_cols_max) {
+      if (sv->box[0]) {  // a larger boundary than the one attached before: nothing may still be running on the old box
+        LBM_CHECK_HIP(hipStreamSynchronize(sv->st));
+        if (sv->far_st) LBM_CHECK_HIP(hipStreamSynchronize(sv->far_st));
+      }
       for (double** p : {&sv->box[0], &sv->box[1], &sv->box_rho, &sv->box_u}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
       }
-      sv->box_rows_max = rows;
-      sv->box_cols_max = cols;
+      sv->box_rows_max = rows > sv->box_rows_max ? rows : sv->box_rows_max;
+      sv->box_cols_max = cols > sv->box_cols_max ? cols : sv->box_cols_max;
+      rows = sv->box_rows_max;
+      cols = sv->box_cols_max;
       sv->box_plane = (long long)rows * cols + 136;
       const size_t n = (size_t)rows * cols;
       LBM_CHECK_HIP(hipMalloc(&sv->box[0], (size_t)sv->box_plane * 9 * sizeof(double)));

@@ -987,3 +987,40 @@ def test_three_slabs_one_exchange_per_several_launches(lib, oracle, D, period):
     torch.cuda.synchronize()
     got = torch.cat([lat[s][cur][:, G:G + R] for s in range(S)], dim=1)
     assert torch.equal(got, a), float((got - a).abs().max())
+
+
+def test_native_ring_mixed_depths_between_exchanges(lib, oracle):
+    """The ring keeps count of the ghost rows that are still current: launches of varying depth on 12 ghost
+    rows skip the exchange whenever this launch AND one more of the same depth fit into what is left, and
+    exchange otherwise.  Self ring; owned rows after every launch == the single block advanced as far."""
+    R, C, G = 128, 192, 12
+    depths = [4, 3, 5, 4, 2, 5, 5, 3]
+    f0 = random_state(oracle, R, C, seed=31)
+    prm = pylbm.BgkParams(1.1, 0)
+    bc = pylbm.Bc.periodic()
+    flat = pylbm.Geom(R, C, 0)
+    p0 = upload_soa(lib, f0)
+    g = pylbm.Geom(R, C, G)
+    lat = [torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+    lat[0][:, G:G + R] = p0
+    lat[1].fill_(float("nan"))
+    ident = (ct.c_ubyte * 128)()
+    ring = ct.c_void_p()
+    lib.ring_unique_id(ident)
+    lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
+    try:
+        torch.cuda.synchronize()
+        lib.ring_exchange(ring, _ptr(lat[0]), None)
+        lib.ring_join(ring, None)
+        a, b = p0.clone(), torch.empty_like(p0)
+        cur = 0
+        for d in depths:
+            lib.ring_bgk_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), ct.byref(bc), ct.byref(prm), d, 16, None)
+            cur ^= 1
+            lib.bgk_stream_collide_xn(_ptr(b), _ptr(a), ct.byref(flat), ct.byref(bc), ct.byref(prm), d, 0, R, None)
+            a, b = b, a
+            torch.cuda.synchronize()
+            got = lat[cur][:, G:G + R]
+            assert torch.equal(got, a), (d, float((got - a).abs().max()))
+    finally:
+        lib.ring_destroy(ring)
