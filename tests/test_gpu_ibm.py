@@ -487,3 +487,35 @@ def test_ring_ibm_block_wrappers_on_a_self_ring(lib, oracle):
     finally:
         lib.ring_destroy(ring)
         sl.close()
+
+
+def test_uniform_field_known_answer_on_the_gpu(lib, oracle):
+    """Known answer of the method itself (not of any restatement): Peskin's kernel is a partition of unity, so in
+    a uniform field one forcing iteration puts exactly -2 rho0 u0 per marker onto the lattice (ibm.cpp:176-182);
+    both forms of the forcing (launch chain: lbm_ibm_force; one workgroup: lbm_ibm_step) and lbm_ibm_surface_force."""
+    X, Y = 96, 88
+    x, y = circle(47.3, 41.6, 14.0)
+    u0, rho0 = np.array([0.043, -0.017]), 1.013
+    u = np.broadcast_to(u0, (X, Y, 2)).copy()
+    rho = np.full((X, Y), rho0)
+    ib = pylbm.Ibm(lib, x, y, X, Y, m_max=2)
+    r0, r1, c0, c1 = ib.roi()
+    ud, rd = upload_soa(lib, u), upload_soa(lib, rho)
+    F = torch.empty((2, r1 - r0, c1 - c0), dtype=torch.float64, device=dev())
+    lib.ibm_force(ib.h, _ptr(ud), _ptr(rd), _ptr(F), None)
+    want = -2.0 * rho0 * u0 * len(x)
+    got = F.sum(dim=(1, 2)).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=0), (got, want)
+    assert np.allclose(ib.surface_force(), want, rtol=1e-12, atol=0)
+    p = torch.zeros((9, X, Y), dtype=torch.float64, device=dev())
+    g = pylbm.Geom(X, Y, 0)
+    lib.ibm_step(ib.h, _ptr(p), ct.byref(g), _ptr(ud), _ptr(rd), ct.c_double(1.3), ct.c_double(3.0), ct.c_double(9.0), None)
+    assert np.allclose(ib.surface_force(), want, rtol=1e-12, atol=0)
+    # Guo's source with a = 1 / cs^2 = 3, b = 1 / cs^4 = 9 (cylinder_test.cpp:116-127): sum_q S_q = 0 and
+    # sum_q c_q S_q = (1 - omega / 2) F at every node, hence over the lattice
+    cx = torch.tensor([0, 1, 0, -1, 0, 1, -1, -1, 1], dtype=torch.float64, device=dev())
+    cy = torch.tensor([0, 0, 1, 0, -1, 1, 1, -1, -1], dtype=torch.float64, device=dev())
+    mom = torch.stack([(p * cx[:, None, None]).sum(), (p * cy[:, None, None]).sum()]).cpu().numpy()
+    assert abs(float(p.sum())) < 1e-12 * abs(want).max()          # no mass
+    assert np.allclose(mom, (1 - 0.5 * 1.3) * want, rtol=1e-10), (mom, (1 - 0.5 * 1.3) * want)
+    ib.close()

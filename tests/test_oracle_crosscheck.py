@@ -65,3 +65,55 @@ def test_static_droplet_restatements_agree(oracle, steps):
         # smooth sigmoid interface: the minority colour is ~1e-11 inside the droplet, which
         # amplifies relative rounding noise between the two summation orders
         assert relerr(a[k], b[k]) < 1e-10, (k, relerr(a[k], b[k]))
+
+
+# ---- known answers of the PUBLISHED algorithm (multi-direct forcing with Peskin's 4-point kernel, src/ibm.cpp:39-45,
+# :158-190): the files that hold it cannot be compiled here, so these pin the restatement to what the method itself
+# guarantees -- independent of either restatement's code ----------------------------------------------------------
+def test_ibm_kernel_is_a_partition_of_unity_uniform_field_known_answer(oracle):
+    """phi sums to 1 over a marker's 4 x 4 box wherever the marker sits, so in a UNIFORM field every marker
+    interpolates exactly (rho0, u0), its force is f_j = -2 rho0 u0 (ibm.cpp:176-178), and spreading moves all
+    of it onto the lattice: after ONE forcing iteration sum_nodes F = -2 rho0 u0 N_markers."""
+    X, Y = 64, 56
+    for cx, cy, radius in ((30.3, 27.6, 9.0), (31.0, 28.5, 12.25), (29.87, 26.11, 5.5)):
+        x, y = circle(cx, cy, radius)
+        u0, rho0 = np.array([0.043, -0.017]), 1.013
+        u = np.broadcast_to(u0, (X, Y, 2)).copy()
+        rho = np.full((X, Y), rho0)
+        F = oracle.ibm_force(x, y, u, rho, m_max=2)
+        total = F.reshape(-1, 2).sum(0)
+        want = -2.0 * rho0 * u0 * len(x)
+        assert np.allclose(total, want, rtol=1e-12, atol=0), (total, want)
+    # no flow, no force
+    assert not oracle.ibm_force(x, y, np.zeros((X, Y, 2)), np.ones((X, Y)), m_max=5).any()
+
+
+def test_ibm_forcing_is_linear_in_the_velocity(oracle):
+    """f_j = -2 rho_j u_j and u <- u + F / (2 rho) are linear in u at fixed rho, through all m_max - 1
+    iterations: F(a u1 + b u2) = a F(u1) + b F(u2)."""
+    X, Y = 48, 44
+    x, y = circle(23.4, 21.7, 8.0)
+    rng = np.random.default_rng(9)
+    u1, u2 = 0.05 * rng.standard_normal((X, Y, 2)), 0.05 * rng.standard_normal((X, Y, 2))
+    rho = 1 + 0.03 * rng.standard_normal((X, Y))
+    F1, F2 = oracle.ibm_force(x, y, u1, rho), oracle.ibm_force(x, y, u2, rho)
+    F12 = oracle.ibm_force(x, y, 0.7 * u1 - 1.9 * u2, rho)
+    assert relerr(F12, 0.7 * F1 - 1.9 * F2) < 1e-12
+
+
+def test_ibm_forcing_moves_with_the_boundary(oracle):
+    """Markers and fields shifted together by whole lattice units (2 rows, 3 columns: exact in floating point for
+    these coordinates): the force field shifts with them, bit for bit -- the ROI origin and the box of a marker
+    are floor-based (ibm.cpp:20-37, :124-153), nothing else knows where the boundary is."""
+    X, Y = 56, 52
+    x, y = circle(24.25, 22.5, 7.0)
+    x, y = np.round(x * 1024) / 1024, np.round(y * 1024) / 1024   # shifts by integers stay exact
+    rng = np.random.default_rng(4)
+    u = 0.05 * rng.standard_normal((X, Y, 2))
+    rho = 1 + 0.02 * rng.standard_normal((X, Y))
+    F0 = oracle.ibm_force(x, y, u, rho)
+    F1 = oracle.ibm_force(x + 2, y + 3, np.roll(u, (2, 3), axis=(0, 1)), np.roll(rho, (2, 3), axis=(0, 1)))
+    r0 = oracle.ibm_roi(x, y)
+    r1 = oracle.ibm_roi(x + 2, y + 3)
+    assert r1 == (r0[0] + 2, r0[1] + 2, r0[2] + 3, r0[3] + 3)
+    assert np.array_equal(F0, F1)
