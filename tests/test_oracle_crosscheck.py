@@ -117,3 +117,29 @@ def test_ibm_forcing_moves_with_the_boundary(oracle):
     r1 = oracle.ibm_roi(x + 2, y + 3)
     assert r1 == (r0[0] + 2, r0[1] + 2, r0[2] + 3, r0[3] + 3)
     assert np.array_equal(F0, F1)
+
+
+def test_colour_gradient_collision_conserves_what_the_method_conserves(oracle):
+    """Known answers of the colour-gradient MRT method itself: the single-phase operator relaxes towards an equilibrium
+    with the node's own rho_k and momentum, the perturbation operator carries neither mass nor momentum, recolouring
+    redistributes the total population between the colours with rho_k fixed (mrtcg_rayleigh_taylor.cpp:212-336).  So
+    at EVERY node, after the whole collision: each colour's mass unchanged, and -- without gravity -- the total
+    momentum unchanged.  Developed Rayleigh-Taylor state (interface, velocities), walls included."""
+    cx = np.array([0, 1, 0, -1, 0, 1, -1, -1, 1.0])
+    cy = np.array([0, 0, 1, 0, -1, 1, 1, -1, -1.0])
+    red, blue = (3.0, 0.7, 0.04, 0.7), (1.0, 0.1, 0.04, -0.7)
+    R, C = 48, 32
+    # develop a flow under gravity, then look at one collision with gravity switched off
+    pg = pyoracle.cg_params(R, C, red=red, blue=blue, sigma=0.1, gravity=6.25e-6)
+    s = oracle.cg_steps(pg, oracle.cg_init(pg), 40)
+    st = {k: s[k] for k in ("f_r", "f_b", "rho_r", "rho_b", "u")}
+    assert np.abs((st["f_r"] + st["f_b"]) @ cx).max() > 1e-5          # there IS momentum to conserve
+    p0 = pyoracle.cg_params(R, C, red=red, blue=blue, sigma=0.1, gravity=0.0)
+    out = oracle.cg_steps(p0, st, 1, want_col=True)
+    for k in ("r", "b"):
+        assert np.abs(out["col_" + k].sum(-1) - st["f_" + k].sum(-1)).max() < 1e-14, k
+    tot0, tot1 = st["f_r"] + st["f_b"], out["col_r"] + out["col_b"]
+    assert np.abs(tot1 @ cx - tot0 @ cx).max() < 1e-15
+    assert np.abs(tot1 @ cy - tot0 @ cy).max() < 1e-15
+    # and the moments the step works with ARE the zeroth moments of its input
+    assert np.abs(st["rho_r"] - st["f_r"].sum(-1)).max() < 1e-14
