@@ -143,3 +143,23 @@ def test_colour_gradient_collision_conserves_what_the_method_conserves(oracle):
     assert np.abs(tot1 @ cy - tot0 @ cy).max() < 1e-15
     # and the moments the step works with ARE the zeroth moments of its input
     assert np.abs(st["rho_r"] - st["f_r"].sum(-1)).max() < 1e-14
+
+
+def test_colour_rest_equilibrium_weights_known_answer(oracle):
+    """Known answer for `colour` (src/colour.cpp:11-64): the rest equilibrium of fluid k is rho_k phi^k with
+    phi^k = (alpha_k, (1 - alpha_k) / 5 x 4, (1 - alpha_k) / 20 x 4) -- a partition of unity whose second moment gives
+    the colour's sound speed 3 (1 - alpha_k) / 5 --, and the shipped parameters balance the two pressures across an
+    interface at rest: rho_r / rho_b = (1 - alpha_b) / (1 - alpha_r)  (mrtcg-rayleigh-taylor-gamma3.toml: 3 / 1, 0.7 / 0.1)."""
+    red, blue = (3.0, 0.7, 0.04, 0.7), (1.0, 0.1, 0.04, -0.7)
+    p = pyoracle.cg_params(48, 32, red=red, blue=blue, sigma=0.1, gravity=0.0)
+    s0 = oracle.cg_init(p)
+    for key, (rho0, alpha, _, _) in (("r", red), ("b", blue)):
+        rho, f = s0["rho_" + key], s0["f_" + key]
+        i = np.unravel_index(np.argmax(rho), rho.shape)
+        assert rho[i] == rho0
+        phi = f[i] / rho[i]
+        want = np.array([alpha] + [(1 - alpha) / 5] * 4 + [(1 - alpha) / 20] * 4)
+        assert np.allclose(phi, want, rtol=1e-14, atol=0), (phi, want)
+        assert abs(phi.sum() - 1) < 1e-15
+    assert np.all(s0["u"] == 0)
+    assert abs(red[0] / blue[0] - (1 - blue[1]) / (1 - red[1])) < 1e-12
