@@ -405,7 +405,10 @@ int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
   // ring plus the fix-ups: 365 VGPRs at 4, 442 at 5; measured 104-108 k vs 94-103 k MLUPS), 3 for KBC
   const lbm_bc& bb = sv->bc;
   const bool walled = bc_is_wall(bb.row_lo) || bc_is_wall(bb.row_hi) || bc_is_wall(bb.col_lo) || bc_is_wall(bb.col_hi);
-  int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 3) : tuning("solver_depth", 5);
+  // (the reference-order BGK collision on a PERIODIC block carries more live values per level: 4 steps per launch read 132.6 k MLUPS at
+  // 8192^2 against 127.1 k with 5, 99.0 k with 3, 120.3 k with 6; the reassociated default 5: 177 / 171 / 143 k at 5 / 6 / 4)
+  const bool ref_order_bgk = sv->model == LBM_MODEL_BGK && !bgk_uses_fast_model(&sv->bgk, &sv->bc);
+  int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 3) : tuning("solver_depth", ref_order_bgk && !sv->ibm && !walled && !bb.pressure_rows ? 4 : 5);
   if (walled && sv->model == LBM_MODEL_BGK && max_depth > tuning("solver_depth_walls", 5)) max_depth = tuning("solver_depth_walls", 5);
   if (walled && sv->model == LBM_MODEL_KBC && max_depth > 3) max_depth = 3;
   for (int i = 0; i < n;) {
