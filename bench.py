@@ -446,7 +446,8 @@ def main():
             "timing": {"protocol": f">= {a.min_warm_s} s of untimed launches after --warmup, then `repeats` batches of `steps` "
                                    "steps, each bracketed by barrier + synchronize, MAX over ranks; value = median batch",
                        "warm_steps_run": warm_steps,
-                       "batch_ms": {"min": round(min(wall) * 1e3, 4), "median": round(dt * 1e3, 4), "max": round(max(wall) * 1e3, 4)},
+                       "batch_ms": {"min": round(min(wall) * 1e3, 4), "median": round(dt * 1e3, 4), "max": round(max(wall) * 1e3, 4),
+                                    "first": round(wall[0] * 1e3, 4), "last": round(wall[-1] * 1e3, 4)},
                        "host_enqueue_ms": round(statistics.median(enq) * 1e3, 4),
                        "timed_region_s": round(sum(wall), 4)},
             "roofline": roof,
