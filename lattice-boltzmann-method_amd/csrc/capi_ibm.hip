@@ -794,7 +794,11 @@ int ibm_box_chain(lbm_ibm* ib, int row_off, int col_off, double* const box[2], i
   const Geom gg = make_geom(*g);
   const int own = ib->d.n_touched <= 4096 ? 4 : 6;
   auto go = [&](auto kern, auto model) -> int {
-    LBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    const unsigned bit = 1u << (16 + (fast_model ? 2 : 0) + (own == 4 ? 0 : 1));
+    if (!(ib->lds_opt_in & bit)) {
+      LBM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      ib->lds_opt_in |= bit;
+    }
     // (at least 100 KB each: one workgroup per compute unit, whatever the forcing itself needs)
     const size_t want = lds > 100 * 1024 ? lds : 100 * 1024;
     LBM_KLAUNCH(kern, dim3(nwg), dim3(1024), want, st, d, ib->m_max, box[*cur], box[*cur ^ 1], gg, model, D, xrho, xu, ib->F_sum,
