@@ -271,6 +271,16 @@ class SlabRing:
             cur.wait_stream(self.side)      # callers synchronise on the current stream
         self.cur ^= 1
 
+    def step_without_exchange(self, step_rows, keep):
+        """A launch-step that uses up ghost rows instead of refreshing them (the schedule of capi_ring.hip's
+        ring_bgk_step on slabs with ghost = m x D rows): ONE call over the owned rows plus `keep` ghost rows per
+        side, which stay current for the launches that follow; the caller makes sure the ghost rows still
+        current before the call are >= keep + the depth of `step_rows`."""
+        src, dst = self.lat[self.cur], self.lat[self.cur ^ 1]
+        assert 0 <= keep < self.ghost
+        step_rows(dst, src, self.geom, self.bc, -keep, self.R + keep)
+        self.cur ^= 1
+
     def autotune(self, step_rows, steps=6, edge_rows=None):
         """Time both overlap schedules (GPU, ghost rows only) and keep the faster; all ranks
         agree through an all-reduce(MAX) of the timings.  Advances the state by 2*steps+2

@@ -112,6 +112,56 @@ def worker(rank, world, port, R, C, steps, f0_path, out_path, depth=1):
     dist.destroy_process_group()
 
 
+def period_worker(rank, world, port, R, C, launches, f0_path, out_path, depth, period):
+    """ghost = period x depth rows: `period - 1` launches without an exchange (owned rows + the ghost rows the
+    later launches still read), then one with it -- the schedule of capi_ring.hip's ring_bgk_step"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pylbm.slab import SlabRing
+    f0 = np.load(f0_path)
+    mine = np.ascontiguousarray(np.moveaxis(f0[rank * R:(rank + 1) * R], -1, 0))
+    G = period * depth
+    ring = SlabRing(None, R, C, rank, world, torch.device("cpu"), periodic=True, plane_pad=5, depth=G)
+    ring.load_precollision(torch.from_numpy(mine), lambda dst, src, geom: dst.copy_(
+        torch.from_numpy(np_collide(src.numpy()))))
+    multi = np_step_rows_xn(depth)
+    valid = G
+    for _ in range(launches):
+        if valid >= 2 * depth:
+            valid -= depth
+            ring.step_without_exchange(multi, valid)
+        else:
+            ring.step(multi, edge_rows=G)
+            valid = G
+    parts = [torch.empty_like(ring.owned().contiguous()) for _ in range(world)]
+    dist.all_gather(parts, ring.owned().contiguous())
+    if rank == 0:
+        np.save(out_path, torch.cat(parts, dim=1).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,depth,period,launches", [(2, 2, 2, 5), (3, 3, 2, 4), (2, 2, 3, 7), (3, 5, 2, 3)])
+def test_slab_ring_one_exchange_per_several_launches(world, depth, period, launches, tmp_path, oracle):
+    """The exchange schedule of the C++ ring on slabs with period x depth ghost rows, across real process
+    boundaries (gloo, 2 and 3 ranks): the partial depth-(period x depth) halo, launches that use ghost rows up
+    instead of refreshing them, also stopping inside a period.  == the single periodic box."""
+    R, C = max(12, 2 * period * depth + 2), 16
+    rng = np.random.default_rng(10 * world + depth)
+    rho = 1 + 0.02 * rng.standard_normal((R * world, C))
+    u = 0.05 * rng.standard_normal((R * world, C, 2))
+    f0 = oracle.equilibrium(u, rho) * (1 + 0.01 * rng.standard_normal((R * world, C, 9)))
+    f0_path, out_path = str(tmp_path / "f0.npy"), str(tmp_path / "p.npy")
+    np.save(f0_path, f0)
+    port = 31500 + (os.getpid() % 2000) + 10 * world + depth + period
+    mp.start_processes(period_worker, args=(world, port, R, C, launches, f0_path, out_path, depth, period), nprocs=world,
+                       join=True, start_method="spawn")
+    p_global = np.moveaxis(np.load(out_path), 0, -1)
+    got = oracle.advect(np.ascontiguousarray(p_global))
+    want, _, _ = oracle.bgk_periodic_steps(f0, OMEGA, 1 + depth * launches)
+    assert np.max(np.abs(got - want)) / np.max(np.abs(want)) < 1e-13
+
+
 @pytest.mark.parametrize("world,depth,steps", [(2, 1, 9), (3, 1, 9), (2, 2, 9), (3, 2, 10), (2, 5, 13), (3, 4, 11)])
 def test_slab_ring_equals_single_box(world, depth, steps, tmp_path, oracle):
     R, C = (6 if depth <= 2 else 12), 16
