@@ -155,6 +155,34 @@ class Box:
             lib.bgk_stream_collide_xn(_ptr(dst), _ptr(src), g, bc, prm, n_steps, 0, self.R, self.stream())
         self.cur ^= 1
 
+    def selfcheck(self, D, world):
+        """Two launches with the ring's default schedule (ghost = period x D rows: the first without an exchange) and
+        the same two with an exchange on every launch, from the same state: owned rows must agree bit for bit on
+        every rank.  The state is restored afterwards."""
+        saved, cur0 = [b.clone() for b in self.buf], self.cur
+        def restore():
+            for b, s_ in zip(self.buf, saved):
+                b.copy_(s_)
+            self.cur = cur0
+            self.lib.ring_exchange(self.ring, _ptr(self.lat[self.cur]), self.stream())
+            self.lib.ring_join(self.ring, self.stream())
+        self.launch(D)
+        self.launch(D)
+        torch.cuda.synchronize()
+        first = self.owned().clone()
+        self.lib.set_tuning(b"ring_period", 1)
+        restore()
+        self.launch(D)
+        self.launch(D)
+        torch.cuda.synchronize()
+        ok = torch.tensor([float(torch.equal(first, self.owned()))], device=self.dev)
+        self.lib.set_tuning(b"ring_period", -1)
+        restore()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return bool(ok.item() > 0)
+
     def advance(self, n):
         """n time steps: n // D window launches, the remainder in single steps"""
         for _ in range(n // self.depth):
@@ -292,6 +320,19 @@ def main():
     f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
     box.load(f0)
     del f0
+
+    # -- slab ring: the one-exchange-per-`period`-launches schedule against one exchange per launch, here and now ----
+    # (N > 1 never ran on hardware before the driver's own scaling run: if the two ever differ on this machine, the
+    # timed run falls back to the plain schedule and says so)
+    ring_check = None
+    if box.ring and box.period > 1 and not a.pmc_child:
+        ring_check = box.selfcheck(D, world)
+        if "ring_period" in tune:
+            lib.set_tuning(b"ring_period", int(tune["ring_period"]))
+        if not ring_check:
+            print("bench.py: ring schedules differ -- falling back to one exchange per launch", file=sys.stderr, flush=True)
+            lib.set_tuning(b"ring_period", 1)
+            box.period = 1
 
     if a.pmc_child:   # under rocprofv3 --pmc: a few launches of the dominant kernel, nothing else
         for _ in range(8):
@@ -451,7 +492,8 @@ def main():
                        "host_enqueue_ms": round(statistics.median(enq) * 1e3, 4),
                        "timed_region_s": round(sum(wall), 4)},
             "roofline": roof,
-            "check": {"total_mass": float(mass), "expected_mass": float(R * C * world)},
+            "check": {"total_mass": float(mass), "expected_mass": float(R * C * world),
+                      **({"ring_schedules_agree_bitwise": ring_check} if ring_check is not None else {})},
         }
         if phases:
             out["ring_phases"] = phases
