@@ -413,7 +413,8 @@ int lbm_ring_join(lbm_ring* rg, lbm_stream_t main);
  * On a closed (periodic) ring whose slabs carry ghost = m x n_steps rows (m = 2, 3; ghost <= 15) only
  * every m-th call exchanges -- all m x n_steps ghost rows in one message; the calls in between are one
  * plain launch over the owned rows plus the ghost rows the later calls of the period still read.  The
- * owned rows are current after EVERY call; any lbm_ring_exchange* starts a new period. */
+ * owned rows are current after EVERY call; any lbm_ring_exchange* starts a new period.  lbm_ring_kbc_step
+ * follows the same rule (ghost = m x n_steps, n_steps <= 4). */
 int lbm_ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
                       const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main);
 /* the same for KBC (n_steps 1, or 2..4 with the reassociated collision) */

@@ -393,6 +393,16 @@ int lbm_ring_kbc_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
   lbm_bc b = bc ? *bc : lbm_bc{0, 0, 0, 0, 0, 1.0, 1.0, 0.0, 0.0};
   if (rg->prev >= 0) b.row_lo = LBM_EDGE_HALO;
   if (rg->next >= 0) b.row_hi = LBM_EDGE_HALO;
+  if (n_steps > 1 && rg->closed && tuning("ring_period", 0) != 1 && rg->valid >= 2 * n_steps) {
+    // ghost = m x n_steps rows on a closed ring: no exchange on this launch (see ring_bgk_step)
+    const int e = rg->valid - n_steps;
+    lbm_geom g2 = rg->g;
+    g2.plane_stride = make_geom(rg->g).plane;
+    g2.R = R + 2 * e;
+    g2.ghost = G - e;
+    rg->valid = e;
+    return lbm_kbc_stream_collide_xn(dst, src, &g2, &b, prm, n_steps, 0, g2.R, main_s);
+  }
   auto rows = [&](int r0, int r1, hipStream_t st) -> int {
     if (n_steps == 1) return lbm_kbc_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
     return lbm_kbc_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);

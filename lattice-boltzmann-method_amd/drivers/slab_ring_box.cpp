@@ -6,7 +6,7 @@
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_box --id-file /tmp/x [...]   under any launcher
 //
 // Options: --rows R (per GPU, weak scaling) --cols C --steps K (launch-steps timed) --warmup W
-//          --depth D (time steps per launch, 1..6; KBC: 1..4) --period P (BGK: launches per halo exchange,
+//          --depth D (time steps per launch, 1..6; KBC: 1..4) --period P (launches per halo exchange,
 //          ghost rows = P x D; default 2) --edge-rows E --omega w
 //          --model bgk|kbc (kbc: the entropic KBC collision with s2 = omega, config 3 over slabs)
 //          --check 1 (N ranks vs rank 0 recomputing the whole box: small sizes only)
@@ -88,8 +88,8 @@ double* make_slab(const Args& a, int R, int row0, int Rg, const lbm_geom& g, con
 int run_rank(const Args& a, int rank, int world, int local_rank) {
   check(lbm_set_device(local_rank), "lbm_set_device");
   const int R = a.rows, C = a.cols, D = a.depth, Rg = R * world;
-  // ghost = period x D rows: lbm_ring_bgk_step exchanges once per `period` launches (BGK; KBC: every launch)
-  const int G = D * ((a.kbc || D < 2) ? 1 : a.period);
+  // ghost = period x D rows: lbm_ring_bgk_step / _kbc_step exchange once per `period` launches
+  const int G = D * (D < 2 ? 1 : a.period);
   lbm_geom g{R, C, G, 0};
   lbm_bgk_params prm{};
   prm.omega = a.omega;

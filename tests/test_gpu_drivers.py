@@ -149,8 +149,8 @@ def test_slab_ring_box_driver_self_ring(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["check"] == "bitwise equal to one block" and line["depth"] == depth
-        # BGK window launches: ghost = period x depth rows, one exchange per `period` launches
-        assert line["ghost_rows"] == (depth * period if model == "bgk" and depth > 1 else depth)
+        # window launches: ghost = period x depth rows, one exchange per `period` launches
+        assert line["ghost_rows"] == (depth * period if depth > 1 else depth)
 
 
 def test_slab_ring_rt_driver(tmp_path):

@@ -216,7 +216,7 @@ def test_native_ring_kbc_self_exchange(lib, oracle):
     prm = pylbm.KbcParams(S2)
     flat = pylbm.Geom(R, C, 0)
     ident = (ct.c_ubyte * 128)()
-    for depth, launches in ((3, 3), (1, 4)):
+    for depth, launches, period in ((3, 3, 1), (3, 5, 2), (2, 7, 3), (1, 4, 1)):   # (the last case feeds the oracle check below)
         n = depth * launches
         # reference: the same number of single steps on one ghost-free block
         a = upload_soa(lib, f0)
@@ -228,9 +228,11 @@ def test_native_ring_kbc_self_exchange(lib, oracle):
             a, tmp = tmp, a
         torch.cuda.synchronize()
         want = tmp
-        g = pylbm.Geom(R, C, depth)
-        lat = [torch.zeros((9, R + 2 * depth, C), dtype=torch.float64, device=d) for _ in range(2)]
-        lat[0][:, depth:depth + R] = first
+        G = depth * period   # period > 1: one exchange per `period` launches, the others use ghost rows up
+        g = pylbm.Geom(R, C, G)
+        lat = [torch.zeros((9, R + 2 * G, C), dtype=torch.float64, device=d) for _ in range(2)]
+        lat[0][:, G:G + R] = first
+        lat[1].fill_(float("nan"))
         ring = ct.c_void_p()
         lib.ring_unique_id(ident)
         lib.ring_create(ct.byref(ring), ident, 0, 1, ct.byref(g), 1)
@@ -243,7 +245,7 @@ def test_native_ring_kbc_self_exchange(lib, oracle):
                 lib.ring_kbc_step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), None, ct.byref(prm), depth, 16, None)
                 cur ^= 1
             torch.cuda.synchronize()
-            assert torch.equal(lat[cur][:, depth:depth + R], want), (depth, float((lat[cur][:, depth:depth + R] - want).abs().max()))
+            assert torch.equal(lat[cur][:, G:G + R], want), (depth, period, float((lat[cur][:, G:G + R] - want).abs().max()))
         finally:
             lib.ring_destroy(ring)
     m0 = oracle.calc_rho(f0)
