@@ -159,7 +159,9 @@ int lbm_slab_ibm_create(lbm_slab_ibm** out, const lbm_geom* slab, int slab_row0,
       if (e == hipSuccess) e = hipMalloc(p, xb);
     if (e == hipSuccess) e = hipMalloc(&sl->xrho, xn * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&sl->xu, 2 * xn * sizeof(double));
-    if (e == hipSuccess && make_background_stream(&sl->bgst) != LBM_OK) e = hipErrorUnknown;
+    // (ordinary priority: with the lowest one a co-owner's block took 1.15 instead of 0.70 ms in a running chain --
+    // profiles/r02_cylinder_emulated_8_slabs_events.txt; one block on lbm_solver_step does not care, 75 / 96 / 119 k either way)
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl->bgst, hipStreamNonBlocking);
     sl->boxed = e == hipSuccess;
   }
   if (e != hipSuccess) {
@@ -315,7 +317,7 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
     // dropped anyway), while the band as a whole takes the D-step window like any far row (unforced: right everywhere
     // outside the box ROI +- D, which is then overwritten with the forced result).  The band lattice stays the whole
     // band at time t / t + D on both co-owners, so nothing changes in what travels between them.  The chain of small
-    // launches stays on the caller's stream; both window launches go to a lowest-priority stream beside it.
+    // launches stays on the caller's stream; both window launches go to a stream of their own beside it.
     const int v0 = sl->b0 + D - sl->row0, v1 = sl->b1 - D - sl->row0;
     o0 = v0 < 0 ? 0 : v0;
     o1 = v1 > R ? R : v1;

@@ -33,5 +33,5 @@ struct lbm_slab_ibm {
   lbm_geom xg;           // box lattice: band rows x (bc1 - bc0) columns
   double* box[2];
   double *xrho, *xu;
-  hipStream_t bgst;      // lowest priority: the window launches (band + far rows) beside the box chain
+  hipStream_t bgst;      // the window launches (band + far rows) beside the box chain
 };

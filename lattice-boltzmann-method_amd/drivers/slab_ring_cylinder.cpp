@@ -261,24 +261,33 @@ int run_emulated(const Args& a, int N) {
   }
   int cur = 0;
   const int wb = (a.warmup + D - 1) / D, nb = (a.steps + D - 1) / D, steps = nb * D;
+  // Per-slab time of a block = HIP events on the caller's stream around its compute and finish calls (the helper
+  // streams inside are joined before the call returns its stream).  All slabs of a block are enqueued back to back and
+  // read at the end of the block: each slab runs alone on the GPU, and while it does the host is already enqueuing
+  // the next one -- what a rank of a running chain sees, not the host's launch latency of a cold start per block.
+  std::vector<void*> ev(4 * N, nullptr);
+  for (auto& e : ev) check(lbm_event_create(&e), "lbm_event_create");
   for (int i = 0; i < wb + nb; ++i) {
-    for (int r = 0; r < N; ++r) {  // each slab alone on the GPU: its own time per block
-      check(lbm_stream_sync(nullptr), "sync");
-      auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < N; ++r) {
+      check(lbm_event_record(ev[4 * r], nullptr), "event");
       check(lbm_slab_ibm_block_compute(S[r].sl, S[r].lat[cur ^ 1], S[r].lat[cur], S[r].buf[0][0], S[r].buf[1][0], nullptr), "lbm_slab_ibm_block_compute");
-      check(lbm_stream_sync(nullptr), "sync");
-      if (i >= wb) S[r].ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      check(lbm_event_record(ev[4 * r + 1], nullptr), "event");
     }
     deliver(false);
     for (int r = 0; r < N; ++r) {
-      check(lbm_stream_sync(nullptr), "sync");
-      auto t0 = std::chrono::steady_clock::now();
+      check(lbm_event_record(ev[4 * r + 2], nullptr), "event");
       check(lbm_slab_ibm_block_finish(S[r].sl, S[r].lat[cur ^ 1], S[r].buf[0][1], S[r].buf[1][1], nullptr), "lbm_slab_ibm_block_finish");
-      check(lbm_stream_sync(nullptr), "sync");
-      if (i >= wb) S[r].ms += 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      check(lbm_event_record(ev[4 * r + 3], nullptr), "event");
+    }
+    for (int r = 0; r < N; ++r) {
+      float m0 = 0, m1 = 0;
+      check(lbm_event_elapsed_ms(&m0, ev[4 * r], ev[4 * r + 1]), "elapsed");
+      check(lbm_event_elapsed_ms(&m1, ev[4 * r + 2], ev[4 * r + 3]), "elapsed");
+      if (i >= wb) S[r].ms += m0 + m1;
     }
     cur ^= 1;
   }
+  for (auto& e : ev) lbm_event_destroy(e);
   double Fs[2] = {0, 0};
   int first_owner = -1, bad = 0;
   for (int r = 0; r < N; ++r)
