@@ -12,6 +12,8 @@
 //   slab_ring_cylinder --spawn N [--rows R_per_gpu] [--cols C] [--steps K] [--warmup W]
 //                      [--diameter D] [--centre-row r] [--depth 5] [--edge-rows E] [--check 1]
 //   slab_ring_cylinder --emulate N ...   ONE process / one GPU playing all N slabs of the chain in turn
+//        --slab-rows r0,r1,...  (emulate) one height per slab instead of N x --rows: a chain runs at its slowest slab's pace,
+//        and the slabs that carry the forced band should own fewer rows
 //                      (messages moved by device copies; per-slab time per block reported; --check 1
 //                      compares with the single-block run bit for bit -- the 8 x 2048 x 4096 layout of
 //                      BASELINE config 5 fits one MI355X several times over)
@@ -33,6 +35,7 @@ struct Args {
   int rows = 2048, cols = 4096, steps = 50, warmup = 5, edge_rows = 32, check = 0, diameter = 300;
   int depth = 5, centre_row = -1, emulate = 0;
   std::string id_file;
+  std::string slab_rows;  // --emulate: comma-separated slab heights (default: N x --rows)
 };
 const double kTau = 0.55, kUin = 0.04, kGuoA = 1.0 / 3.0, kGuoB = 1.0 / 9.0;  // cylinder_test.cpp:66-67
 
@@ -202,16 +205,31 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
 // --emulate N: every slab of the chain in turn on ONE GPU, messages by device copies
 int run_emulated(const Args& a, int N) {
   check(lbm_set_device(0), "lbm_set_device");
-  const int D = a.depth, R = a.rows, C = a.cols, Rg = R * N, G = D;
-  lbm_geom g{R, C, G, 0};
+  const int D = a.depth, C = a.cols, G = D;
+  // slab heights: uniform, or as listed (a load-balanced decomposition gives the slabs that share the forced band
+  // fewer rows: their block carries the band's chain on top of their far rows)
+  std::vector<int> rows(N, a.rows), row0(N, 0);
+  if (!a.slab_rows.empty()) {
+    size_t pos = 0;
+    for (int r = 0; r < N; ++r) {
+      const size_t end = a.slab_rows.find(',', pos);
+      rows[r] = std::atoi(a.slab_rows.substr(pos, end == std::string::npos ? std::string::npos : end - pos).c_str());
+      if (rows[r] <= 0) throw std::runtime_error("--slab-rows needs one positive height per slab");
+      pos = end == std::string::npos ? a.slab_rows.size() : end + 1;
+    }
+  }
+  int Rg = 0;
+  for (int r = 0; r < N; ++r) row0[r] = Rg, Rg += rows[r];
   lbm_bgk_params prm{};
   prm.omega = 1.0 / kTau;
   prm.delta_form = 1;
   lbm_bc bc = global_bc();
   std::vector<double> mx, my;
   cylinder_markers(Rg, C, a.centre_row, a.diameter, mx, my);
-  const size_t n = (size_t)R * C, plane = (size_t)(R + 2 * G) * C;
   struct Slab {
+    int R = 0, row0 = 0;
+    size_t n = 0, plane = 0;
+    lbm_geom g{};
     lbm_slab_ibm* sl = nullptr;
     double* lat[2] = {nullptr, nullptr};
     double* buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [side][send / recv], sized for the priming messages
@@ -221,11 +239,16 @@ int run_emulated(const Args& a, int N) {
   std::vector<Slab> S(N);
   int b0 = 0, b1 = 0;
   for (int r = 0; r < N; ++r) {
-    check(lbm_slab_ibm_create(&S[r].sl, &g, r * R, Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB), "lbm_slab_ibm_create");
+    S[r].R = rows[r];
+    S[r].row0 = row0[r];
+    S[r].n = (size_t)rows[r] * C;
+    S[r].plane = (size_t)(rows[r] + 2 * G) * C;
+    S[r].g = lbm_geom{rows[r], C, G, 0};
+    check(lbm_slab_ibm_create(&S[r].sl, &S[r].g, S[r].row0, Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB), "lbm_slab_ibm_create");
     check(lbm_slab_ibm_info(S[r].sl, &S[r].owner, &S[r].sp, &S[r].sn, &b0, &b1), "lbm_slab_ibm_info");
     for (int k = 0; k < 2; ++k) {
-      check(lbm_malloc((void**)&S[r].lat[k], 9 * plane * 8), "lbm_malloc");
-      check(lbm_memset(S[r].lat[k], 0, 9 * plane * 8, nullptr), "memset");
+      check(lbm_malloc((void**)&S[r].lat[k], 9 * S[r].plane * 8), "lbm_malloc");
+      check(lbm_memset(S[r].lat[k], 0, 9 * S[r].plane * 8, nullptr), "memset");
     }
     for (int side = 0; side < 2; ++side) {
       long long cs = 0, cr = 0;
@@ -249,7 +272,7 @@ int run_emulated(const Args& a, int N) {
   {  // first iteration (:103-127) from the uniform inflow state
     std::vector<double*> pre(N);
     for (int r = 0; r < N; ++r) {
-      pre[r] = uniform_inflow(R, C, G);
+      pre[r] = uniform_inflow(S[r].R, C, G);
       check(lbm_slab_ibm_prime_pack(S[r].sl, pre[r], S[r].buf[0][0], S[r].buf[1][0], nullptr), "lbm_slab_ibm_prime_pack");
     }
     deliver(true);
@@ -311,11 +334,14 @@ int run_emulated(const Args& a, int N) {
     lbm_geom gg;
     check(lbm_solver_lattices(sv, &cl, &ol, &gg), "lbm_solver_lattices");
     const long long ps = gg.plane_stride ? gg.plane_stride : (long long)Rg * C;
-    std::vector<double> want(n), got(n);
+    std::vector<double> want, got;
     for (int q = 0; q < 9; ++q)
       for (int r = 0; r < N; ++r) {
-        check(lbm_memcpy_d2h(want.data(), cl + q * ps + (size_t)r * n, n * 8, nullptr), "d2h");
-        check(lbm_memcpy_d2h(got.data(), S[r].lat[cur] + q * plane + (size_t)G * C, n * 8, nullptr), "d2h");
+        const size_t n = S[r].n;
+        want.resize(n);
+        got.resize(n);
+        check(lbm_memcpy_d2h(want.data(), cl + q * ps + (size_t)S[r].row0 * C, n * 8, nullptr), "d2h");
+        check(lbm_memcpy_d2h(got.data(), S[r].lat[cur] + q * S[r].plane + (size_t)G * C, n * 8, nullptr), "d2h");
         check(lbm_solver_sync(sv), "sync");
         check(lbm_stream_sync(nullptr), "sync");
         if (std::memcmp(want.data(), got.data(), n * 8) != 0) ++bad;
@@ -327,12 +353,15 @@ int run_emulated(const Args& a, int N) {
     lbm_ibm_destroy(ibw);
     lbm_free(prew);
   }
+  double slowest = 0;
+  for (int r = 0; r < N; ++r) slowest = std::max(slowest, S[r].ms / nb);
   std::printf("{\"driver\": \"slab_ring_cylinder\", \"mode\": \"emulated chain on one GPU\", \"slabs\": %d, \"rows_per_slab\": %d, "
-              "\"cols\": %d, \"global_rows\": %d, \"markers\": %d, \"band_rows\": [%d, %d], \"steps_per_block\": %d, \"steps\": %d, \"per_slab\": [",
-              N, R, C, Rg, (int)mx.size(), b0, b1, D, steps);
+              "\"cols\": %d, \"global_rows\": %d, \"markers\": %d, \"band_rows\": [%d, %d], \"steps_per_block\": %d, \"steps\": %d, "
+              "\"slowest_slab_ms_per_block\": %.4f, \"chain_mlups_at_the_slowest_slabs_pace\": %.1f, \"per_slab\": [",
+              N, a.slab_rows.empty() ? a.rows : 0, C, Rg, (int)mx.size(), b0, b1, D, steps, slowest, (double)Rg * C * D / slowest / 1e3);
   for (int r = 0; r < N; ++r)
-    std::printf("%s{\"slab\": %d, \"owner\": %d, \"straddle_prev\": %d, \"straddle_next\": %d, \"ms_per_block\": %.4f, \"mlups\": %.1f}",
-                r ? ", " : "", r, S[r].owner, S[r].sp, S[r].sn, S[r].ms / nb, (double)R * C * D / (S[r].ms / nb) / 1e3);
+    std::printf("%s{\"slab\": %d, \"rows\": %d, \"owner\": %d, \"straddle_prev\": %d, \"straddle_next\": %d, \"ms_per_block\": %.4f, \"mlups\": %.1f}",
+                r ? ", " : "", r, S[r].R, S[r].owner, S[r].sp, S[r].sn, S[r].ms / nb, (double)S[r].R * C * D / (S[r].ms / nb) / 1e3);
   std::printf("], \"Fs\": [%.17g, %.17g]%s}\n", Fs[0], Fs[1],
               a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
   std::fflush(stdout);
@@ -354,6 +383,7 @@ int main(int argc, char** argv) {
   a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "32").c_str());
   a.depth = std::atoi(arg_value(argc, argv, "--depth", "5").c_str());
   a.centre_row = std::atoi(arg_value(argc, argv, "--centre-row", "-1").c_str());
+  a.slab_rows = arg_value(argc, argv, "--slab-rows", "");
   a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.diameter = std::atoi(arg_value(argc, argv, "--diameter", "300").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
