@@ -12,11 +12,11 @@
 //   slab_ring_cylinder --spawn N [--rows R_per_gpu] [--cols C] [--steps K] [--warmup W]
 //                      [--diameter D] [--centre-row r] [--depth 5] [--edge-rows E] [--check 1]
 //   slab_ring_cylinder --emulate N ...   ONE process / one GPU playing all N slabs of the chain in turn
-//        --slab-rows r0,r1,...  (emulate) one height per slab instead of N x --rows: a chain runs at its slowest slab's pace,
-//        and the slabs that carry the forced band should own fewer rows
 //                      (messages moved by device copies; per-slab time per block reported; --check 1
 //                      compares with the single-block run bit for bit -- the 8 x 2048 x 4096 layout of
 //                      BASELINE config 5 fits one MI355X several times over)
+//                      --slab-rows r0,r1,...: one height per slab instead of N x --rows -- a chain runs at its
+//                      slowest slab's pace, and the slabs that carry the forced band should own fewer rows
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_cylinder --id-file /tmp/x ...
 //
 // tau = 0.55 (parameters.toml), u_in = 0.04 (SURVEY 8d allows a smaller u for the benchmark), markers
