@@ -202,6 +202,24 @@ def test_slab_ring_cylinder_emulated_chain_with_the_cylinder_on_a_seam(tmp_path)
     assert roles == [(1, 0, 1), (1, 1, 0), (0, 0, 0), (0, 0, 0)], roles
 
 
+def test_slab_ring_cylinder_emulated_chain_with_unequal_slab_heights(tmp_path):
+    """--slab-rows: each slab brings its own height (a chain runs at its slowest slab's pace, so the slabs that carry
+    the forced band get fewer rows).  The band inside one short slab, and straddling two short ones; == the single
+    block bit for bit."""
+    import json
+    exe = os.path.join(BIN, "slab_ring_cylinder")
+    for heights, centre, roles_want in (("112,72,104,96", 148, [(0, 0, 0), (1, 0, 0), (0, 0, 0), (0, 0, 0)]),
+                                        ("104,80,88,112", 184, [(0, 0, 0), (1, 0, 1), (1, 1, 0), (0, 0, 0)])):
+        r = subprocess.run([exe, "--emulate", "4", "--slab-rows", heights, "--cols", "160", "--diameter", "22", "--centre-row", str(centre),
+                            "--steps", "15", "--warmup", "5", "--check", "1"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["check"] == "bitwise equal to one block" and line["global_rows"] == 384
+        assert [s["rows"] for s in line["per_slab"]] == [int(h) for h in heights.split(",")]
+        roles = [(s["owner"], s["straddle_prev"], s["straddle_next"]) for s in line["per_slab"]]
+        assert roles == roles_want, roles
+
+
 def test_ulbm_poiseuille_driver_vs_oracle(tmp_path, oracle):
     """drivers/ulbm_poiseuille.cpp (KBC + pressure rows + bounce-back columns from the driver's zero
     start) at the reference's 128 x 128 for 300 iterations: moments as the driver holds them."""
