@@ -311,7 +311,44 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
   hipStream_t st = as_stream(s);
   int rc = LBM_OK;
   int o0 = R, o1 = R;  // owned rows [o0, o1) come from the band; everything else is far
-  if (sl->owner && sl->boxed && tuning("ibm_box", 1)) {
+  if (sl->owner && sl->boxed && !sl->straddle_prev && !sl->straddle_next && tuning("ibm_box", 1) && tuning("ibm_box_sole", 1)) {
+    // SOLE owner (the whole valid band inside this slab's rows; its outer D rows at most in the ghost rows): the band
+    // lattice would only mirror rows this slab holds anyway.  So, as lbm_solver_step does on one block: the box straight
+    // out of the slab lattice, the D-step window over ALL owned rows beside the chain, the box ROI +- D straight back --
+    // no band window launch, no copy of 300-odd full-width rows per block (31 us), one far launch instead of three.
+    const int Rb = sl->bg.R, Cb = sl->xg.C, br0 = sl->b0 - sl->row0;  // box row 0 in slab rows (>= -ghost)
+    const lbm_bc pb{LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, LBM_EDGE_PERIODIC, 0, 1.0, 1.0, 0.0, 0.0};
+    LBM_CHECK_HIP(hipEventRecord(sl->ev_fork, st));
+    rc = box_copy(sl->box[0], sl->xg, 0, 0, src, sl->g, br0, sl->bc0, Rb, Cb, st);
+    if (rc) return rc;
+    int cur = 0;
+    rc = tuning("ibm_chain_kernel", 0) ? ibm_box_chain(sl->ib, 0, sl->bc0, sl->box, &cur, &sl->xg, &sl->prm, bgk_uses_fast_model(&sl->prm, &pb), D,
+                                                       sl->xrho, sl->xu, sl->ga, sl->gb, st)
+                                       : 1;
+    if (rc < 0) return rc;
+    const bool one_launch = rc == 0;
+    LBM_CHECK_HIP(hipStreamWaitEvent(sl->bgst, sl->ev_fork, 0));
+    rc = one_launch ? ibm_gate(sl->ib, sl->bgst) : LBM_OK;
+    if (!rc) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, 0, R, sl->bgst);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipEventRecord(sl->ev_join, sl->bgst));
+    for (int k = 1; k <= D && !one_launch && !rc; ++k) {  // cylinder_test.cpp:103-127 on the shrinking trapezoid
+      rc = lbm_bgk_stream_collide(sl->box[cur ^ 1], sl->box[cur], &sl->xg, &pb, &sl->prm, k, Rb - k, sl->xrho, sl->xu, s);
+      if (!rc) rc = ibm_step_window(sl->ib, 0, sl->bc0, sl->box[cur ^ 1], &sl->xg, sl->xu, sl->xrho, sl->prm.omega, sl->ga, sl->gb, st);
+      cur ^= 1;
+    }
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipStreamWaitEvent(st, sl->ev_join, 0));
+    rc = box_copy(dst, sl->g, br0 + D, sl->bc0 + D, sl->box[cur], sl->xg, D, D, Rb - 2 * D, Cb - 2 * D, st);
+    if (rc) return rc;
+    sl->blat_stale = true;
+    o0 = 0, o1 = R;  // (nothing left for the far launches below)
+  } else if (sl->owner && sl->boxed && tuning("ibm_box", 1)) {
+    if (sl->blat_stale) {  // the band lattice fell behind while the slab lattice was worked on directly: all its rows are here
+      rc = lbm_rows_copy(sl->blat[sl->bcur], &sl->bg, 0, src, &sl->g, sl->b0 - sl->row0, sl->bg.R, s);
+      if (rc) return rc;
+      sl->blat_stale = false;
+    }
     // The forcing reaches a node only through the ROI, so the D forced single steps are cut to a BOX -- band rows x
     // columns ROI +- 2 D -- held as a small periodic lattice pair of its own (what its wrap spoils is the frame that is
     // dropped anyway), while the band as a whole takes the D-step window like any far row (unforced: right everywhere
@@ -363,6 +400,11 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
     if (!rc) rc = lbm_rows_copy(dst, &sl->g, o0, bn, &sl->bg, o0 + sl->row0 - sl->b0, o1 - o0, s);
     if (rc) return rc;
   } else if (sl->owner) {
+    if (sl->blat_stale) {
+      rc = lbm_rows_copy(sl->blat[sl->bcur], &sl->bg, 0, src, &sl->g, sl->b0 - sl->row0, sl->bg.R, s);
+      if (rc) return rc;
+      sl->blat_stale = false;
+    }
     const int v0 = sl->b0 + D - sl->row0, v1 = sl->b1 - D - sl->row0;
     o0 = v0 < 0 ? 0 : v0;
     o1 = v1 > R ? R : v1;
@@ -392,7 +434,7 @@ int lbm_slab_ibm_block_compute(lbm_slab_ibm* sl, double* dst, const double* src,
     if (rc) return rc;
     LBM_CHECK_HIP(hipEventRecord(sl->ev_join, sl->aux));
   }
-  const bool boxed = sl->owner && sl->boxed && tuning("ibm_box", 1);
+  const bool boxed = sl->owner && sl->boxed && tuning("ibm_box", 1);  // (both boxed forms have launched their far rows)
   if (!boxed) {
     // far rows: plain D-step window from the time-t lattice
     if (o0 > 0) rc = lbm_bgk_stream_collide_xn(dst, src, &sl->g, &sl->bc, &sl->prm, D, 0, o0 < R ? o0 : R, st);

@@ -34,4 +34,5 @@ struct lbm_slab_ibm {
   double* box[2];
   double *xrho, *xu;
   hipStream_t bgst;      // the window launches (band + far rows) beside the box chain
+  bool blat_stale;       // a sole owner's boxed blocks work on the slab lattice directly: the band lattice is behind
 };
