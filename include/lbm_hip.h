@@ -605,7 +605,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * 1: they may use the reassociated model too, 1e-10 instead of bitwise on the cylinder preset), "ibm_depth" (steps lbm_solver_step advances per block on a BGK lattice with an immersed boundary: forced
  * band around the ROI in single steps, rows at least that far away through the multi-step window; default 5,
  * 1 = one step per launch everywhere; same bits), "pressure_depth" (steps per block on lattices with pressure-periodic rows: the 2 D rows on either side of the virtual rows in single steps on a small periodic
- * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ibm_box" (0: the forced single steps of an immersed-boundary block run over full-width band rows instead of a box of ROI +- 2 D rows and columns), "ibm_box_overlap" (0: box chain and window launch one after the other on the caller's stream), "ibm_box_sole" (0: a slab that owns the whole forced band alone still goes through the band lattice), "ibm_chain_kernel" (1: the forced-box chain of a block as ONE launch of "ibm_chain_wgs" [16] workgroups with grid barriers instead of 3 D launches; same bits, level), "bg_priority" (0: the background stream of those window launches gets default instead of lowest priority), "ring_period" (1: lbm_ring_bgk_step exchanges on every launch even when the slabs carry m x n_steps ghost rows; default 0 = one exchange per m launches), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
+ * lattice beside the D-step window on all other rows; default 5 for BGK, 2 for KBC, 1 = one step per launch; same bits), "halo_grid" (workgroup cap of the halo pack / unpack copies, default 256), "ibm_box" (0: the forced single steps of an immersed-boundary block run over full-width band rows instead of a box of ROI +- 2 D rows and columns), "ibm_box_overlap" (0: box chain and window launch one after the other on the caller's stream), "ibm_box_sole" (0: a slab that owns the whole forced band alone still goes through the band lattice), "ibm_chain_kernel" (1: the forced-box chain of a block as ONE launch of "ibm_chain_wgs" [16] workgroups with grid barriers instead of 3 D launches; same bits, level), "bg_priority" (1: the background stream of those window launches gets the lowest priority; default 0: such a queue starves while any other queue of the process has work), "ring_period" (1: lbm_ring_bgk_step exchanges on every launch even when the slabs carry m x n_steps ghost rows; default 0 = one exchange per m launches), "ibm_gate" (1 [default]: lbm_solver_step holds its lattice launches behind a one-wave gate until the
  * forcing workgroup is resident; 0: off), "sw_split" (1 [default]: wall-bounded
  * multi-step launches run their wall-free interior through the plain instantiation and only the frame of
  * outermost strips / rows next to a wall row through the wall-carrying one, on a helper stream; 0: one

@@ -195,7 +195,10 @@ int box_copy(double* dst, const lbm_geom& dg, int dst_row, int dst_col, const do
 }
 int make_background_stream(hipStream_t* out) {
   int lo = 0, hi = 0;  // (numerically: lo = least urgent)
-  if (tuning("bg_priority", 1) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+  // ("bg_priority" = 1: lowest priority.  Level with the default on one block, 75 / 96 / 119 k either way -- but a
+  // lowest-priority queue STARVES while any other queue of the process has work: a co-owner slab's window launches
+  // took 1.15 instead of 0.70 ms per block in a running chain, profiles/r02_cylinder_emulated_8_slabs_events.txt)
+  if (tuning("bg_priority", 0) && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
       hipStreamCreateWithPriority(out, hipStreamNonBlocking, lo) == hipSuccess)
     return LBM_OK;
   (void)hipGetLastError();

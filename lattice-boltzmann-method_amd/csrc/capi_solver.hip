@@ -37,7 +37,7 @@ struct lbm_solver {
   double *box_rho = nullptr, *box_u = nullptr;
   long long box_plane = 0;
   int box_rows_max = 0, box_cols_max = 0;
-  hipStream_t far_st = nullptr;  // the D-step window over the whole lattice, beside the box chain; lowest priority
+  hipStream_t far_st = nullptr;  // the D-step window over the whole lattice, beside the box chain
   hipEvent_t ev_far_fork = nullptr, ev_far_join = nullptr;
   // pressure-periodic rows at multi-step speed (solver_pressure_block): two small lattices of 4 D rows
   // holding the rows on both sides of the virtual rows, advanced in single steps on a helper stream
@@ -274,8 +274,7 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
   // steps as little as rows that far away do.  So the trapezoid is cut in both directions -- rows and columns ROI +- 2 D
   // (columns widened to multiples of 8) copied into a small periodic lattice pair, D forced single steps there (what its
   // wrap spoils is the frame that is dropped anyway), the box ROI +- D copied back -- and the D-step window runs over
-  // ALL rows from the time-t lattice, on a low-priority stream of its own beside the chain of small launches on the
-  // caller's stream.
+  // ALL rows from the time-t lattice, on a stream of its own beside the chain of small launches on the caller's stream.
   // ("ibm_box" = 0: the full-width band below; also taken when the box would touch a wall column.)
   const int bc0 = (c0 - 2 * D) / 8 * 8, bc1 = (c1 + 2 * D + 7) / 8 * 8;
   if (sv->box[0] && sv->far_st && tuning("ibm_box", 1) && c0 - 2 * D >= 8 && bc1 <= sv->g.C - 1 && bc1 - bc0 <= sv->box_cols_max &&

@@ -39,8 +39,9 @@ bool bgk_uses_fast_model(const lbm_bgk_params* prm, const lbm_bc* bc);
 // indices, ghost rows allowed)
 int box_copy(double* dst, const lbm_geom& dg, int dst_row, int dst_col, const double* src, const lbm_geom& sg,
              int src_row, int src_col, int n_rows, int n_cols, hipStream_t st);
-// capi_core.hip: a non-blocking stream of the LOWEST priority, for a grid-filling launch that runs beside a chain of
-// small dependent kernels on the caller's stream: the dispatcher then hands freed wave slots to the chain first.
+// capi_core.hip: a non-blocking stream for a grid-filling launch that runs beside a chain of small dependent kernels
+// on the caller's stream ("bg_priority" = 1: of the lowest priority, so that the dispatcher hands freed wave slots to
+// the chain first -- off by default: such a queue starves whenever another queue of the process has work).
 // (A stream that spares one compute unit for the chain -- hipExtStreamCreateWithCUMask -- was tried and is far slower:
 // profiles/r02_ibm_box_bench.log.)
 int make_background_stream(hipStream_t* out);

@@ -248,7 +248,7 @@ def test_forced_band_blocks_equal_single_steps(lib, oracle, cx_frac):
     ({"ibm_box": 1, "ibm_box_overlap": 0}, 0.55),    # forced box, window launch behind the chain on one stream
     ({"ibm_box": 1, "ibm_step_chain": 1}, 0.55),     # box; forcing as the 10-launch chain
     ({"ibm_box": 1, "ibm_step_opt": 0, "ibm_step_split": 0}, 0.55),  # box; the one-workgroup kernel of round 1
-    ({"ibm_box": 1, "bg_priority": 0}, 0.55),
+    ({"ibm_box": 1, "bg_priority": 1}, 0.55),
     ({"ibm_box": 1, "ibm_chain_kernel": 1}, 0.55),   # box; the chain as ONE launch of 16 workgroups with grid barriers
     ({"ibm_box": 1, "ibm_chain_kernel": 1, "ibm_chain_wgs": 5}, 0.55),
     ({"ibm_box": 1, "ibm_chain_kernel": 1, "ibm_chain_wgs": 40, "ibm_box_overlap": 0}, 0.55),
