@@ -13,8 +13,9 @@
  * so that a wavefront reads 64 consecutive doubles of one population.  lbm_aos_to_soa /
  * lbm_soa_to_aos convert bit-exactly: AoS element ((r*C)+c)*Q+q  <->  SoA q*R*C + r*C + c.
  * Scalar fields: rho[R][C]; vector fields u[2][R][C] (component slowest).
- * A lattice with ghost rows (multi-GPU slabs) stores planes of (R+2) rows: row index
- * r in [-1, R] lives at plane offset (r+1)*C; see lbm_geom.
+ * A lattice with g ghost rows per side (multi-GPU slabs; g = the steps per launch D, or m x D with one
+ * exchange per m launches, or 3 for the two-phase step) stores planes of (R+2g) rows: row index r in
+ * [-g, R+g) lives at plane offset (r+g)*C; see lbm_geom.
  *
  * All functions return 0 (LBM_OK) or a negative status and never throw; the message of
  * the last failure on the calling thread is lbm_last_error_string().  Calls enqueue work
@@ -388,17 +389,36 @@ int lbm_solver_attach_ibm(lbm_solver* sv, lbm_ibm* ib, double guo_a, double guo_
  * that drive lbm_*_stream_collide themselves (benchmarks, multi-GPU slabs) */
 int lbm_solver_lattices(lbm_solver* sv, double** cur, double** other, lbm_geom* geom /* may be NULL */);
 
-/* ---- slab ring in C++: one process per GPU, RCCL send/recv on packed halo buffers ------------------
- * Native counterpart of pylbm/slab.py (same kernels, same halo sets): edge rows + pack + ONE
- * ncclSend/ncclRecv pair per neighbour + unpack on the ring's own high-priority stream, interior rows
- * on the caller's stream.  RCCL is dlopen()ed on first use.  Rank 0 calls lbm_ring_unique_id and
- * distributes the 128 bytes by any means (file, MPI, torch.distributed); every rank then calls
- * lbm_ring_create with its slab geometry (ghost = halo depth). */
+/* ---- slab ring in C++: one process per GPU, packed halo messages between row slabs ------------------
+ * Native counterpart of pylbm/slab.py (same kernels, same halo sets): edge rows + pack + ONE message
+ * to and from each neighbour + unpack on the ring's own high-priority stream, interior rows on the
+ * caller's stream (the block binding of test/decompose_domain.cpp:181-187, generalised to D ghost rows).
+ * Two transports carry the messages:
+ *   LBM_RING_RCCL  ncclSend / ncclRecv in one group (RCCL is dlopen()ed on first use): the default;
+ *   LBM_RING_IPC   peer-mapped direct stores: every rank owns a receive window in device memory that its
+ *                  neighbours map through hipIpcMemHandle_t; a message is stored straight into the
+ *                  neighbour's window and announced by a sequence word (bounded device-side waits,
+ *                  lbm_ring_status).  One node; also between processes that share ONE GPU, where RCCL
+ *                  refuses to run.  Same bits either way.
+ *   LBM_RING_DEFAULT = environment LBM_RING_TRANSPORT ("rccl" | "ipc"), else RCCL.
+ * Rank 0 calls lbm_ring_unique_id(_ex) and distributes the 128 bytes by any means (file, MPI,
+ * torch.distributed); every rank then calls lbm_ring_create(_ex) with its slab geometry (ghost = halo
+ * depth; same columns and ghost rows on every rank). */
+#define LBM_RING_DEFAULT (-1)
+#define LBM_RING_RCCL 0
+#define LBM_RING_IPC 1
 typedef struct lbm_ring lbm_ring;
 int lbm_ring_unique_id(unsigned char* id128);
+int lbm_ring_unique_id_ex(unsigned char* id128, int transport);
 int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nranks,
                     const lbm_geom* slab, int periodic);
+int lbm_ring_create_ex(lbm_ring** out, const unsigned char* id128, int rank, int nranks,
+                       const lbm_geom* slab, int periodic, int transport);
 int lbm_ring_destroy(lbm_ring* rg);
+int lbm_ring_transport(const lbm_ring* rg); /* LBM_RING_RCCL or LBM_RING_IPC */
+/* LBM_OK, or LBM_ERR_STATE once a bounded wait of the peer-mapped transport has given up on a neighbour
+ * (tuning "ring_ipc_timeout_ms", default 20000): everything computed since is void.  Host-side read, no sync. */
+int lbm_ring_status(const lbm_ring* rg);
 /* refresh the ghost rows of `lattice` (ordered after the work enqueued on `after`); asynchronous */
 int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after);
 /* same with complete ghost rows (LBM_HALO_FULL): the initial fill before multi-step launches on a
@@ -497,6 +517,7 @@ typedef struct lbm_slab_pressure lbm_slab_pressure;
 int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
                              const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth);
 int lbm_slab_pressure_destroy(lbm_slab_pressure* sl);
+int lbm_slab_pressure_info(const lbm_slab_pressure* sl, int* R, int* C, int* ghost, int* depth); /* any output may be NULL */
 long long lbm_slab_pressure_msg_doubles(const lbm_slab_pressure* sl, int side, int start /* 1: the start-up exchange */);
 /* start-up from the driver's pre-collision state: exchange, then first iteration into `post` */
 int lbm_slab_pressure_start_pack(lbm_slab_pressure* sl, const double* pre, double* send_prev, double* send_next, lbm_stream_t s);

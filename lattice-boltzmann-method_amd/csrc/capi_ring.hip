@@ -3,15 +3,22 @@
 // counterpart of pylbm/slab.py (which drives the same kernels through torch.distributed); both
 // implement the block binding of test/decompose_domain.cpp:181-187 generalised to D ghost rows.
 //
-// RCCL is dlopen()ed on first use (librccl.so of the hosting process if one is already mapped,
-// e.g. PyTorch's, else the ROCm one): liblbm_hip.so itself has no link-time dependency on it.
+// Two transports carry the packed messages (lbm_ring_create_ex): RCCL send / recv (the default; dlopen()ed on
+// first use -- the librccl.so.1 of the hosting process if one is already mapped, e.g. PyTorch's, else the ROCm
+// one: liblbm_hip.so itself has no link-time dependency on it) and peer-mapped direct stores into the
+// neighbour's receive window (capi_ring_ipc.hip; also works between processes that share ONE GPU, which RCCL
+// refuses).  What travels and when is the same for both.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
 #include "d2q9.hpp"
 #include "internal.hpp"
+#include "ring_ipc.hpp"
 #include "slab_ibm.hpp"
 
 namespace {
@@ -38,7 +45,9 @@ Rccl g_rccl;
 
 int load_rccl() {
   if (g_rccl.h) return LBM_OK;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // the soname first: inside a process that already maps an RCCL (PyTorch's librccl.so.1) that is the one to join --
+  // the bare "librccl.so" can resolve to /opt/rocm/lib and put a SECOND runtime beside it
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
   for (const char* n : names) {
     h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -79,7 +88,11 @@ int load_rccl() {
 }  // namespace
 
 struct lbm_ring {
-  ncclComm_t comm;
+  int transport;                 // LBM_RING_RCCL / LBM_RING_IPC
+  ncclComm_t comm;               // RCCL
+  lbm::IpcTransport* ipc;        // peer-mapped windows
+  size_t bufsz;                  // doubles each send / receive buffer holds
+  int skipped;                   // launches without an exchange since the last one (their ghost rows are used up)
   int rank, nranks, next, prev;  // neighbours, -1 = none (chain end)
   lbm_geom g;                    // slab geometry (ghost = halo depth)
   size_t msg;                    // doubles per packed message
@@ -98,8 +111,24 @@ using namespace lbm;
 
 extern "C" {
 
-int lbm_ring_unique_id(unsigned char* id128) {
+static int default_transport() {
+  const char* e = std::getenv("LBM_RING_TRANSPORT");
+  if (e && (!std::strcmp(e, "ipc") || !std::strcmp(e, "peer") || !std::strcmp(e, "1"))) return LBM_RING_IPC;
+  return LBM_RING_RCCL;
+}
+
+int lbm_ring_unique_id_ex(unsigned char* id128, int transport) {
   LBM_REQUIRE(id128, "lbm_ring_unique_id: NULL buffer");
+  if (transport == LBM_RING_DEFAULT) transport = default_transport();
+  if (transport == LBM_RING_IPC) {
+    // any 128 bytes no other ring of this node uses: they name the rendezvous segment
+    const int fd = open("/dev/urandom", O_RDONLY);
+    const bool ok = fd >= 0 && read(fd, id128, 128) == 128;
+    if (fd >= 0) close(fd);
+    LBM_REQUIRE(ok, "lbm_ring_unique_id: cannot read /dev/urandom");
+    return LBM_OK;
+  }
+  LBM_REQUIRE(transport == LBM_RING_RCCL, "lbm_ring_unique_id: unknown transport %d", transport);
   int rc = load_rccl();
   if (rc) return rc;
   ncclUniqueId id;
@@ -107,17 +136,23 @@ int lbm_ring_unique_id(unsigned char* id128) {
   std::memcpy(id128, id.internal, 128);
   return LBM_OK;
 }
+int lbm_ring_unique_id(unsigned char* id128) { return lbm_ring_unique_id_ex(id128, LBM_RING_DEFAULT); }
 
-int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nranks,
-                    const lbm_geom* slab, int periodic) {
+int lbm_ring_create_ex(lbm_ring** out, const unsigned char* id128, int rank, int nranks, const lbm_geom* slab,
+                       int periodic, int transport) {
   LBM_REQUIRE(out && id128 && slab, "lbm_ring_create: NULL argument");
   LBM_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "lbm_ring_create: rank %d of %d", rank, nranks);
   LBM_REQUIRE(slab->ghost >= 1 && slab->ghost <= 15, "lbm_ring_create: slab needs 1..15 ghost rows (ghost=%d)", slab->ghost);
-  int rc = load_rccl();
-  if (rc) return rc;
+  if (transport == LBM_RING_DEFAULT) transport = default_transport();
+  LBM_REQUIRE(transport == LBM_RING_RCCL || transport == LBM_RING_IPC, "lbm_ring_create: unknown transport %d", transport);
+  if (transport == LBM_RING_RCCL) {
+    int rc = load_rccl();
+    if (rc) return rc;
+  }
   lbm_ring* rg = new (std::nothrow) lbm_ring();
   LBM_REQUIRE(rg, "lbm_ring_create: out of host memory");
   std::memset(rg, 0, sizeof *rg);
+  rg->transport = transport;
   rg->rank = rank;
   rg->nranks = nranks;
   rg->next = (periodic || rank < nranks - 1) ? (rank + 1) % nranks : -1;
@@ -125,22 +160,31 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
   rg->closed = periodic ? 1 : 0;
   rg->g = *slab;
   rg->msg = (size_t)lbm_halo_rows(slab->ghost) * slab->C;
-  ncclUniqueId id;
-  std::memcpy(id.internal, id128, 128);
-  ncclResult_t nr = g_rccl.CommInitRank(&rg->comm, nranks, id, rank);
-  if (nr != 0) {
-    set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(nr));
-    delete rg;
-    return LBM_ERR_HIP;
+  // room for the two-colour message of the two-phase step when the slab has its 3 ghost rows
+  size_t bufsz = (size_t)lbm_halo_rows(LBM_HALO_FULL(slab->ghost)) * slab->C;  // complete ghost rows (walls)
+  if (slab->ghost == 3 && bufsz < 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C) bufsz = 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C;
+  rg->bufsz = bufsz;
+  if (transport == LBM_RING_RCCL) {
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128, 128);
+    ncclResult_t nr = g_rccl.CommInitRank(&rg->comm, nranks, id, rank);
+    if (nr != 0) {
+      set_error("ncclCommInitRank failed: %s", g_rccl.GetErrorString(nr));
+      delete rg;
+      return LBM_ERR_HIP;
+    }
+  } else {
+    int rc = ipc_create(&rg->ipc, id128, rank, nranks, rg->prev, rg->next, bufsz);
+    if (rc) {
+      delete rg;
+      return rc;
+    }
   }
   int lo = 0, hi = 0;
   hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
   if (e == hipSuccess) e = hipStreamCreateWithPriority(&rg->edge, hipStreamNonBlocking, hi);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->main_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&rg->edge_done, hipEventDisableTiming);
-  // room for the two-colour message of the two-phase step when the slab has its 3 ghost rows
-  size_t bufsz = (size_t)lbm_halo_rows(LBM_HALO_FULL(slab->ghost)) * slab->C;  // complete ghost rows (walls)
-  if (slab->ghost == 3 && bufsz < 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C) bufsz = 2 * (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * slab->C;
   for (double** p : {&rg->send_next, &rg->send_prev, &rg->recv_prev, &rg->recv_next})
     if (e == hipSuccess) e = hipMalloc(p, bufsz * sizeof(double));
   if (e != hipSuccess) {
@@ -150,6 +194,23 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
   }
   *out = rg;
   return LBM_OK;
+}
+
+int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nranks,
+                    const lbm_geom* slab, int periodic) {
+  return lbm_ring_create_ex(out, id128, rank, nranks, slab, periodic, LBM_RING_DEFAULT);
+}
+
+int lbm_ring_transport(const lbm_ring* rg) { return rg ? rg->transport : LBM_ERR_INVALID; }
+
+// 0 while every message has arrived; the peer-mapped transport's bounded waits report here when a neighbour
+// never delivered (1) or never acknowledged (2) -- the launch chain still drains, its results are void
+int lbm_ring_status(const lbm_ring* rg) {
+  LBM_REQUIRE(rg, "lbm_ring_status: NULL ring");
+  const int st = rg->ipc ? ipc_status(rg->ipc) : 0;
+  if (st) set_error("lbm_ring: a neighbour of rank %d never %s within the time limit (\"ring_ipc_timeout_ms\")", rg->rank,
+                    st == 1 ? "delivered its message" : "acknowledged a message");
+  return st ? LBM_ERR_STATE : LBM_OK;
 }
 
 int lbm_ring_destroy(lbm_ring* rg) {
@@ -168,7 +229,24 @@ int lbm_ring_destroy(lbm_ring* rg) {
   }
   if (rg->edge) (void)hipStreamDestroy(rg->edge);
   if (rg->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(rg->comm);
+  if (rg->ipc) ipc_destroy(rg->ipc);
   delete rg;
+  return LBM_OK;
+}
+
+// One message to and one from each neighbour, enqueued on the ring's edge stream (counts in doubles; 0 = none)
+static int ring_transfer(lbm_ring* rg, const double* send_prev, size_t n_send_prev, double* recv_prev, size_t n_recv_prev,
+                         const double* send_next, size_t n_send_next, double* recv_next, size_t n_recv_next) {
+  if (rg->transport == LBM_RING_IPC)
+    return ipc_sendrecv(rg->ipc, send_prev, n_send_prev, recv_prev, n_recv_prev, send_next, n_send_next, recv_next, n_recv_next, rg->edge);
+  LBM_CHECK_NCCL(g_rccl.GroupStart());
+  // sends (to next, to prev), receives (from prev, from next): with two ranks both neighbours
+  // are the same peer and messages match in issue order
+  if (rg->next >= 0 && n_send_next) LBM_CHECK_NCCL(g_rccl.Send(send_next, n_send_next, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  if (rg->prev >= 0 && n_send_prev) LBM_CHECK_NCCL(g_rccl.Send(send_prev, n_send_prev, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->prev >= 0 && n_recv_prev) LBM_CHECK_NCCL(g_rccl.Recv(recv_prev, n_recv_prev, kNcclFloat64, rg->prev, rg->comm, rg->edge));
+  if (rg->next >= 0 && n_recv_next) LBM_CHECK_NCCL(g_rccl.Recv(recv_next, n_recv_next, kNcclFloat64, rg->next, rg->comm, rg->edge));
+  LBM_CHECK_NCCL(g_rccl.GroupEnd());
   return LBM_OK;
 }
 
@@ -180,7 +258,9 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
   // two lattices = the two colours; full = complete ghost rows (multi-step launches with walls)
   const int G = lattice2 ? LBM_HALO_TWO_PHASE : (full ? LBM_HALO_FULL(rg->g.ghost) : rg->g.ghost);
   const size_t msg = (size_t)lbm_halo_rows(G) * rg->g.C;
+  LBM_REQUIRE(msg * (lattice2 ? 2 : 1) <= rg->bufsz, "lbm_ring: message of %zu doubles, buffers of %zu", msg * (lattice2 ? 2 : 1), rg->bufsz);
   rg->valid = lattice2 ? 3 : rg->g.ghost;  // these ghost rows are current again
+  rg->skipped = 0;
   if (as_stream(after) != rg->edge) {
     LBM_CHECK_HIP(hipEventRecord(rg->main_done, as_stream(after)));
     LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
@@ -198,14 +278,11 @@ static int ring_exchange(lbm_ring* rg, double* lattice, double* lattice2, lbm_st
       if (rc) return rc;
     }
   }
-  LBM_CHECK_NCCL(g_rccl.GroupStart());
-  // sends (to next, to prev), receives (from prev, from next): with two ranks both neighbours
-  // are the same peer and messages match in issue order
-  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_next, count, kNcclFloat64, rg->next, rg->comm, rg->edge));
-  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Send(rg->send_prev, count, kNcclFloat64, rg->prev, rg->comm, rg->edge));
-  if (rg->prev >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_prev, count, kNcclFloat64, rg->prev, rg->comm, rg->edge));
-  if (rg->next >= 0) LBM_CHECK_NCCL(g_rccl.Recv(rg->recv_next, count, kNcclFloat64, rg->next, rg->comm, rg->edge));
-  LBM_CHECK_NCCL(g_rccl.GroupEnd());
+  {
+    const size_t np = rg->prev >= 0 ? count : 0, nn = rg->next >= 0 ? count : 0;
+    int rc = ring_transfer(rg, rg->send_prev, np, rg->recv_prev, np, rg->send_next, nn, rg->recv_next, nn);
+    if (rc) return rc;
+  }
   for (int k = 0; k < nl; ++k) {
     if (rg->prev >= 0) {
       int rc = lbm_halo_unpack(lats[k], rg->recv_prev + k * msg, &rg->g, G, 0, rg->edge);
@@ -330,8 +407,20 @@ static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main,
   return LBM_OK;
 }
 
+// A launch that exchanges still READS n_steps ghost rows of src.  After launches without an exchange only rg->valid of them
+// are current: a deeper launch than the rows left (depths 2,2,2,5 on 10 ghost rows leave 4) refreshes src's ghost rows first.
+static int ring_refresh_if_used_up(lbm_ring* rg, const double* src, int n_steps, bool full, hipStream_t main) {
+  if (!rg->skipped || rg->valid >= n_steps) return LBM_OK;
+  int rc = ring_exchange(rg, const_cast<double*>(src), nullptr, main, full);
+  if (rc) return rc;
+  LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+  LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+  return LBM_OK;
+}
+
 static int ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc* bc,
-                         const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s, bool may_skip) {
+                         const lbm_bgk_params* prm, int n_steps, int edge_rows, lbm_stream_t main_s, bool may_skip,
+                         bool force_full = false) {
   LBM_REQUIRE(rg && dst && src && prm, "lbm_ring_bgk_step: NULL argument");
   const int R = rg->g.R, G = rg->g.ghost;
   LBM_REQUIRE(n_steps >= 1 && n_steps <= G, "lbm_ring_bgk_step: %d steps with %d ghost rows", n_steps, G);
@@ -356,10 +445,17 @@ static int ring_bgk_step(lbm_ring* rg, double* dst, const double* src, const lbm
     g2.R = R + 2 * e;
     g2.ghost = G - e;
     rg->valid = e;
+    rg->skipped += 1;
     return lbm_bgk_stream_collide_xn(dst, src, &g2, &b, prm, n_steps, 0, g2.R, main_s);
   }
-  // walls + several steps per launch: the NEXT launch reads complete ghost rows
-  const bool full = n_steps > 1 && (bc_is_wall(b.row_lo) || bc_is_wall(b.row_hi) || bc_is_wall(b.col_lo) || bc_is_wall(b.col_hi));
+  // walls + several steps per launch: the NEXT launch reads complete ghost rows (force_full: a neighbour that owns an
+  // immersed-boundary band always sends and expects complete rows, whatever the columns are)
+  // (G > 1, not n_steps > 1: a single-step launch may be followed by a multi-step one that reads what travels now)
+  const bool full = force_full || (G > 1 && (bc_is_wall(b.row_lo) || bc_is_wall(b.row_hi) || bc_is_wall(b.col_lo) || bc_is_wall(b.col_hi)));
+  {
+    int rc = ring_refresh_if_used_up(rg, src, n_steps, full, as_stream(main_s));
+    if (rc) return rc;
+  }
   auto rows = [&](int r0, int r1, hipStream_t st) -> int {
     if (n_steps == 1) return lbm_bgk_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
     return lbm_bgk_stream_collide_xn(dst, src, &rg->g, &b, prm, n_steps, r0, r1, st);
@@ -401,7 +497,12 @@ int lbm_ring_kbc_step(lbm_ring* rg, double* dst, const double* src, const lbm_bc
     g2.R = R + 2 * e;
     g2.ghost = G - e;
     rg->valid = e;
+    rg->skipped += 1;
     return lbm_kbc_stream_collide_xn(dst, src, &g2, &b, prm, n_steps, 0, g2.R, main_s);
+  }
+  {
+    int rc = ring_refresh_if_used_up(rg, src, n_steps, false, as_stream(main_s));
+    if (rc) return rc;
   }
   auto rows = [&](int r0, int r1, hipStream_t st) -> int {
     if (n_steps == 1) return lbm_kbc_stream_collide(dst, src, &rg->g, &b, prm, r0, r1, nullptr, nullptr, st);
@@ -521,12 +622,11 @@ static int ring_sendrecv(lbm_ring* rg, const double* send_prev, size_t n_send_pr
                          hipStream_t after) {
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, after));
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
-  LBM_CHECK_NCCL(g_rccl.GroupStart());
-  if (rg->next >= 0 && n_send_next) LBM_CHECK_NCCL(g_rccl.Send(send_next, n_send_next, kNcclFloat64, rg->next, rg->comm, rg->edge));
-  if (rg->prev >= 0 && n_send_prev) LBM_CHECK_NCCL(g_rccl.Send(send_prev, n_send_prev, kNcclFloat64, rg->prev, rg->comm, rg->edge));
-  if (rg->prev >= 0 && n_recv_prev) LBM_CHECK_NCCL(g_rccl.Recv(recv_prev, n_recv_prev, kNcclFloat64, rg->prev, rg->comm, rg->edge));
-  if (rg->next >= 0 && n_recv_next) LBM_CHECK_NCCL(g_rccl.Recv(recv_next, n_recv_next, kNcclFloat64, rg->next, rg->comm, rg->edge));
-  LBM_CHECK_NCCL(g_rccl.GroupEnd());
+  {
+    int rc = ring_transfer(rg, send_prev, rg->prev >= 0 ? n_send_prev : 0, recv_prev, rg->prev >= 0 ? n_recv_prev : 0, send_next,
+                           rg->next >= 0 ? n_send_next : 0, recv_next, rg->next >= 0 ? n_recv_next : 0);
+    if (rc) return rc;
+  }
   LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
   LBM_CHECK_HIP(hipStreamWaitEvent(after, rg->edge_done, 0));
   return LBM_OK;
@@ -592,11 +692,13 @@ int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const do
   LBM_REQUIRE((!sl->has_prev || rg->prev >= 0) && (!sl->has_next || rg->next >= 0),
               "lbm_ring_bgk_block_ibm: the slab has a neighbour the ring does not know");
   // (every launch with its exchange: the band's co-owners exchange every block too)
-  if (!sl->owner) return ring_bgk_step(rg, dst, src, &sl->bc_global, &sl->prm, sl->D, edge_rows, main_s, false);
+  // (complete ghost rows on every seam: that is what an owner next door sends and unpacks, also with periodic columns)
+  if (!sl->owner) return ring_bgk_step(rg, dst, src, &sl->bc_global, &sl->prm, sl->D, edge_rows, main_s, false, true);
   hipStream_t main = as_stream(main_s);
   int rc = lbm_slab_ibm_block_compute(sl, dst, src, rg->send_prev, rg->send_next, main_s);
   if (rc) return rc;
   const size_t msg = (size_t)lbm_slab_ibm_msg_doubles(sl);
+  LBM_REQUIRE(msg <= rg->bufsz, "lbm_ring_bgk_block_ibm: messages of %zu doubles, ring buffers of %zu", msg, rg->bufsz);
   rc = ring_sendrecv(rg, rg->send_prev, msg, rg->recv_prev, msg, rg->send_next, msg, rg->recv_next, msg, main);
   if (rc) return rc;
   return lbm_slab_ibm_block_finish(sl, dst, rg->recv_prev, rg->recv_next, main_s);
@@ -606,6 +708,14 @@ int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const do
 int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, lbm_stream_t main_s) {
   LBM_REQUIRE(rg && sl && post && pre, "lbm_ring_pressure_start: NULL argument");
   LBM_REQUIRE(rg->prev >= 0 && rg->next >= 0 && rg->nranks >= 2, "lbm_ring_pressure_start: needs a periodic ring of at least 2 slabs");
+  {
+    int R = 0, C = 0, ghost = 0, D = 0;
+    int rc = lbm_slab_pressure_info(sl, &R, &C, &ghost, &D);
+    if (rc) return rc;
+    LBM_REQUIRE(rg->g.R == R && rg->g.C == C && rg->g.ghost == ghost && ghost >= D,
+                "lbm_ring_pressure_start: ring (%d x %d, %d ghost rows) and slab (%d x %d, %d ghost rows, blocks of %d) differ",
+                rg->g.R, rg->g.C, rg->g.ghost, R, C, ghost, D);
+  }
   const size_t n_prev = (size_t)lbm_slab_pressure_msg_doubles(sl, 0, 1), n_next = (size_t)lbm_slab_pressure_msg_doubles(sl, 1, 1);
   // (the partner of a seam sends what this side receives: the start-up messages across the pressure seam are both 2 D rows)
   double* buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -633,10 +743,18 @@ int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, d
 int lbm_ring_bgk_block_pressure(lbm_ring* rg, lbm_slab_pressure* sl, double* dst, const double* src, lbm_stream_t main_s) {
   LBM_REQUIRE(rg && sl && dst && src, "lbm_ring_bgk_block_pressure: NULL argument");
   LBM_REQUIRE(rg->prev >= 0 && rg->next >= 0, "lbm_ring_bgk_block_pressure: needs a periodic ring");
+  const size_t msg = (size_t)lbm_slab_pressure_msg_doubles(sl, 0, 0);
+  {
+    int R = 0, C = 0, ghost = 0, D = 0;
+    int rc = lbm_slab_pressure_info(sl, &R, &C, &ghost, &D);
+    if (rc) return rc;
+    LBM_REQUIRE(rg->g.R == R && rg->g.C == C && rg->g.ghost == ghost && ghost >= D && msg <= rg->bufsz,
+                "lbm_ring_bgk_block_pressure: ring (%d x %d, %d ghost rows) and slab (%d x %d, %d ghost rows, blocks of %d) differ",
+                rg->g.R, rg->g.C, rg->g.ghost, R, C, ghost, D);
+  }
   hipStream_t main = as_stream(main_s);
   int rc = lbm_slab_pressure_block_compute(sl, dst, src, rg->send_prev, rg->send_next, main_s);
   if (rc) return rc;
-  const size_t msg = (size_t)lbm_slab_pressure_msg_doubles(sl, 0, 0);
   rc = ring_sendrecv(rg, rg->send_prev, msg, rg->recv_prev, msg, rg->send_next, msg, rg->recv_next, msg, main);
   if (rc) return rc;
   return lbm_slab_pressure_block_finish(sl, dst, rg->recv_prev, rg->recv_next, main_s);

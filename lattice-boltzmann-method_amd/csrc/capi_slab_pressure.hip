@@ -39,6 +39,15 @@ inline long long plane_of(const lbm_geom& g) { return g.plane_stride > 0 ? g.pla
 
 extern "C" {
 
+int lbm_slab_pressure_info(const lbm_slab_pressure* sl, int* R, int* C, int* ghost, int* depth) {
+  LBM_REQUIRE(sl, "lbm_slab_pressure_info: NULL slab");
+  if (R) *R = sl->g.R;
+  if (C) *C = sl->g.C;
+  if (ghost) *ghost = sl->g.ghost;
+  if (depth) *depth = sl->D;
+  return LBM_OK;
+}
+
 int lbm_slab_pressure_destroy(lbm_slab_pressure* sl) {
   if (!sl) return LBM_OK;
   if (sl->aux) {

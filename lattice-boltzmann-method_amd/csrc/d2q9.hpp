@@ -834,10 +834,14 @@ __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const doub
 #pragma unroll
     for (int q = 0; q < Q; ++q) cur[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
   }
+  // the column the wall fix-ups see: with wall columns the raw one (lanes beyond the lattice hold no node), with
+  // periodic columns the WRAPPED one -- a lane left of column 0 holds a real node of a wall ROW and needs its fix-ups
+  // like any other (row walls + periodic columns: the corner lanes fed garbage into the valid columns before)
+  const int c_bc = walled_cols ? c_raw : c;
   for (int i = 0; i < n_iter; i += 3) {
-    sw_iteration<Model, D, 0, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
-    sw_iteration<Model, D, 1, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
-    sw_iteration<Model, D, 2, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c, bc, c_raw);
+    sw_iteration<Model, D, 0, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc);
+    sw_iteration<Model, D, 1, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc);
+    sw_iteration<Model, D, 2, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc);
   }
 }
 

@@ -712,6 +712,74 @@ def test_two_slabs_with_walls_multi_step_equal_single_block(lib, oracle, depth):
     assert torch.equal(got, want), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize("rowmode", ["bounce_back", "abb_velocity"])
+@pytest.mark.parametrize("depth", [2, 5])
+def test_window_row_walls_with_periodic_columns(lib, oracle, rowmode, depth):
+    """Wall ROWS + PERIODIC columns in the multi-step window (round 3 fix): the lanes of a strip that lie beyond the
+    lattice hold wrapped columns -- real nodes of the wall rows, whose fix-ups were skipped, so the corners fed
+    garbage (over slabs: NaN from the unused ghost rows behind the wall) into the valid columns.  One block with
+    every frame / interior split and two emulated slabs == single steps, bit for bit."""
+    mode = pylbm.EDGE_BOUNCE_BACK if rowmode == "bounce_back" else pylbm.EDGE_ABB_VELOCITY
+    Rg, C, launches = 128, 150, 2
+    R, D = Rg // 2, depth
+    f0 = random_state(oracle, Rg, C, seed=11)
+    prm = pylbm.BgkParams(1.25, 0)
+    bc_g = pylbm.Bc.periodic()
+    bc_g.row_lo = bc_g.row_hi = mode
+    bc_g.uw_r = 0.03
+    flat = pylbm.Geom(Rg, C, 0)
+    p0 = upload_soa(lib, f0)
+    a, b = p0.clone(), torch.empty_like(p0)
+    for _ in range(D * launches):
+        lib.bgk_stream_collide(_ptr(b), _ptr(a), ct.byref(flat), ct.byref(bc_g), ct.byref(prm), 0, Rg, None, None, None)
+        a, b = b, a
+    torch.cuda.synchronize()
+    want = a
+    try:
+        for split in (0, 1, 2):
+            lib.set_tuning(b"sw_split", split)
+            x, y = p0.clone(), torch.empty_like(p0)
+            for _ in range(launches):
+                lib.bgk_stream_collide_xn(_ptr(y), _ptr(x), ct.byref(flat), ct.byref(bc_g), ct.byref(prm), D, 0, Rg, None)
+                x, y = y, x
+            torch.cuda.synchronize()
+            assert torch.equal(x, want), (split, float((x - want).abs().max()))
+    finally:
+        lib.set_tuning(b"sw_split", -1)
+    geom = pylbm.Geom(R, C, D)
+    bcs = []
+    for s in range(2):
+        bb = pylbm.Bc.periodic()
+        bb.uw_r = 0.03
+        bb.row_lo = mode if s == 0 else pylbm.EDGE_HALO
+        bb.row_hi = pylbm.EDGE_HALO if s == 0 else mode
+        bcs.append(bb)
+    lat = [[torch.zeros((9, R + 2 * D, C), dtype=torch.float64, device=dev()) for _ in range(2)] for _ in range(2)]
+    H = 100 + D
+    msg = torch.empty(lib.raw.lbm_halo_rows(H) * C, dtype=torch.float64, device=dev())
+
+    def halo(cur):
+        lib.halo_pack(_ptr(msg), _ptr(lat[0][cur]), ct.byref(geom), H, 1, None)
+        lib.halo_unpack(_ptr(lat[1][cur]), _ptr(msg), ct.byref(geom), H, 0, None)
+        lib.halo_pack(_ptr(msg), _ptr(lat[1][cur]), ct.byref(geom), H, 0, None)
+        lib.halo_unpack(_ptr(lat[0][cur]), _ptr(msg), ct.byref(geom), H, 1, None)
+
+    for s in range(2):
+        lat[s][0][:, D:D + R] = p0[:, s * R:(s + 1) * R]
+    halo(0)
+    cur = 0
+    for _ in range(launches):
+        for s in range(2):
+            for r0, r1 in ((0, 16), (R - 16, R), (16, R - 16)):
+                lib.bgk_stream_collide_xn(_ptr(lat[s][cur ^ 1]), _ptr(lat[s][cur]), ct.byref(geom), ct.byref(bcs[s]),
+                                          ct.byref(prm), D, r0, r1, None)
+        cur ^= 1
+        halo(cur)
+    torch.cuda.synchronize()
+    got = torch.cat([lat[0][cur][:, D:D + R], lat[1][cur][:, D:D + R]], dim=1)
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
 def test_native_ring_with_wall_columns(lib, oracle):
     """lbm_ring_bgk_step on a channel (bounce-back columns, periodic rows): one rank, self send/recv
     of COMPLETE ghost rows, 4-step launches; equals the single block advanced step by step."""
