@@ -5,6 +5,7 @@ slab-decomposed along rows over N GPUs (weak scaling) with a halo exchange per l
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...          (no WORLD_SIZE in the environment: starts its N ranks itself)
 
 One step = one pass of the hot path over every node of the box (the default launch fuses 5
 steps: `steps` counts time steps, not launches).  Rank 0 prints ONE JSON line.
@@ -14,11 +15,16 @@ Timing protocol: the GPU is first driven until >= 0.3 s of l
 back to back, each repeat bracketed by barrier + synchronize on both sides with the MAX over
 ranks taken per repeat; `ms_per_step` / `value` are those of the MEDIAN repeat.
 
-N > 1: the transport is the library's own slab ring (csrc/capi_ring.hip: RCCL send/recv on packed
-halo buffers on the ring's own high-priority stream, interior rows on the caller's stream);
-torch.distributed only carries the 128-byte RCCL id, the barriers and the MAX reductions.
+N > 1: the transport is the library's own slab ring (csrc/capi_ring.hip: one message to and from each
+neighbour per exchange on the ring's own high-priority stream -- RCCL send/recv by default, peer-mapped
+direct stores with --transport ipc --, interior rows on the caller's stream); torch.distributed only
+carries the 128-byte ring id, the barriers and the MAX reductions.  `--share-gpu` rehearses the N-rank
+run on ONE device (every rank on GPU 0, peer-mapped transport, gloo control plane): plumbing, not a number.
 
-The timed region touches nothing under oracle/; the cpu_baseline leg (rank 0, N = 1 only) times
+N = 1 adds `secondary`: BASELINE configs 3, 4, 5 (KBC 4096^2, two-phase 8192x2048, BGK + immersed
+cylinder 16384x4096) timed after the headline, each with a roofline built the same way.
+
+The timed regions touch nothing under oracle/; the cpu_baseline leg (rank 0, N = 1 only) times
 the unmodified reference (oracle/_ref) or, failing that, the CPU restatement on a bounded sample.
 """
 import argparse
@@ -26,8 +32,11 @@ import ctypes as ct
 import json
 import math
 import os
+import socket
 import statistics
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,20 +44,131 @@ for p in (os.path.join(ROOT, "lattice-boltzmann-method_amd"), os.path.join(ROOT,
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-import pylbm  # noqa: E402
-from pylbm import _ptr  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md:36); measured copy ceiling 6290
 HBM_COPY_CEILING_GBS = 6290.0
 BYTES_PER_LUP = 144.0        # 9 f64 reads + 9 f64 writes, SURVEY 8(d)
 MIN_WARM_S = 0.3             # launches run before anything is timed, whatever --warmup says
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+RING_RCCL, RING_IPC = 0, 1
 
 
-def taylor_green(lib, R_local, C, row0, R_global, dev, U=0.04):
+# =====================================================================================================
+# launcher: `python bench.py --gpus N` with no WORLD_SIZE starts its N ranks itself
+# =====================================================================================================
+def self_launch(a, argv):
+    """One child process per rank, started BEFORE this process touches a GPU; rank 0's JSON line is relayed.
+    A rank that fails ends the others (their exact pids) and its stderr is shown; exit code non-zero."""
+    import torch  # device_count() does not initialise the GPU
+    n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        print("bench.py: no GPU visible (no CPU fallback on the product path)", file=sys.stderr)
+        return 2
+    if a.gpus > n_dev and not a.share_gpu:
+        print(f"bench.py: --gpus {a.gpus} but this machine shows {n_dev} GPU(s).  One rank per GPU is the measured "
+              f"configuration; `--share-gpu` rehearses the {a.gpus}-rank schedule on GPU 0 (peer-mapped transport) "
+              "without producing a scaling number.", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    tmp = tempfile.mkdtemp(prefix="lbm_bench_", dir="/tmp")
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = open(os.path.join(tmp, f"rank{r}.out"), "w")
+        err = open(os.path.join(tmp, f"rank{r}.err"), "w")
+        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out, stderr=err), out, err))
+    t0, why = time.time(), None
+    while any(p.poll() is None for p, _, _ in procs):
+        bad = [r for r, (p, _, _) in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            why = f"rank {bad[0]} exited with code {procs[bad[0]][0].returncode}"
+        elif time.time() - t0 > a.launch_timeout:
+            why = f"no result after {a.launch_timeout} s"
+        if why:
+            for p, _, _ in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t1 = time.time()
+            while any(p.poll() is None for p, _, _ in procs) and time.time() - t1 < 10:
+                time.sleep(0.1)
+            for p, _, _ in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p, out, err in procs:
+        p.wait()
+        out.close()
+        err.close()
+    read = lambda r, ext: open(os.path.join(tmp, f"rank{r}.{ext}")).read()
+    bad = [r for r, (p, _, _) in enumerate(procs) if p.returncode != 0]
+    if why or bad:
+        first = bad[0] if bad else 0
+        print(f"bench.py --gpus {a.gpus}: {why or 'a rank failed'}\n---- stderr of rank {first} ----\n{read(first, 'err')[-4000:]}",
+              file=sys.stderr)
+        return procs[first][0].returncode or 1
+    sys.stderr.write(read(0, "err")[-2000:])
+    lines = [ln for ln in read(0, "out").splitlines() if ln.startswith("{")]
+    if not lines:
+        print("bench.py: rank 0 printed no result line", file=sys.stderr)
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+# =====================================================================================================
+# control plane (torch.distributed: id broadcast, barriers, reductions -- nothing of the data path)
+# =====================================================================================================
+class Ctl:
+    def __init__(self, rank, world, dev, backend):
+        import torch
+        import torch.distributed as dist
+        self.rank, self.world, self.dist, self.torch = rank, world, dist, torch
+        self.dev = dev if backend == "nccl" else torch.device("cpu")
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            if backend == "gloo":
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def reduce(self, values, op):
+        """list of floats -> list of floats, MAX / MIN / SUM over ranks"""
+        if self.world == 1:
+            return list(values)
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN, "sum": self.dist.ReduceOp.SUM}[op])
+        return t.tolist()
+
+    def gather(self, values):
+        if self.world == 1:
+            return [list(values)]
+        t = self.torch.tensor(list(values), dtype=self.torch.float64, device=self.dev)
+        g = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(g, t)
+        return [x.tolist() for x in g]
+
+    def bcast_bytes(self, b):
+        if self.world == 1:
+            return bytes(b)
+        t = self.torch.tensor(list(bytes(b)), dtype=self.torch.uint8, device=self.dev)
+        self.dist.broadcast(t, 0)
+        return bytes(t.cpu().tolist())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def taylor_green(lib, torch, _ptr, R_local, C, row0, R_global, dev, U=0.04):
     """rho = 1, Taylor-Green vortex on the GLOBAL box; returns SoA f = feq(rho, u) [9,R,C]."""
     r = (torch.arange(R_local, device=dev, dtype=torch.float64) + row0).view(-1, 1)
     c = torch.arange(C, device=dev, dtype=torch.float64).view(1, -1)
@@ -99,8 +219,12 @@ class Box:
     """The per-rank slab: two SoA lattices with padded planes and (when split) D ghost rows, the
     launch that advances them, and -- with ghost rows -- the library's slab ring."""
 
-    def __init__(self, lib, a, rank, world, dev, with_ring):
-        self.lib, self.a, self.rank, self.world, self.dev = lib, a, rank, world, dev
+    def __init__(self, lib, a, ctl, dev, with_ring, transport):
+        import torch
+        import pylbm
+        self.torch, self.pylbm = torch, pylbm
+        self.lib, self.a, self.ctl, self.dev = lib, a, ctl, dev
+        rank, world = ctl.rank, ctl.world
         R, C = a.rows, a.cols
         self.R, self.C = R, C
         self.prm = pylbm.BgkParams(a.omega, 0)
@@ -116,28 +240,46 @@ class Box:
         self.buf = [torch.zeros(9 * self.plane, dtype=torch.float64, device=dev) for _ in range(2)]
         self.lat = [b.as_strided((9, rows, C), (self.plane, C, 1)) for b in self.buf]
         self.cur = 0
-        self.ring = None
+        self.ring, self.transport, self.transport_note = None, None, None
         if with_ring:
-            ident = (ct.c_ubyte * 128)()
-            if rank == 0:
-                lib.ring_unique_id(ident)
-            if world > 1:   # torch.distributed carries the id, nothing else of the data path
-                t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
-                dist.broadcast(t, 0)
-                ident = (ct.c_ubyte * 128)(*t.cpu().tolist())
-            self.ring = ct.c_void_p()
-            lib.ring_create(ct.byref(self.ring), ident, rank, world, ct.byref(self.geom), 1)
+            self.ring = self._make_ring(transport)
+            if self.ring is None and transport == RING_RCCL:
+                # RCCL could not be brought up on every rank: the peer-mapped transport needs no RCCL at all
+                self.transport_note = "RCCL ring creation failed on at least one rank; fell back to the peer-mapped transport"
+                self.ring = self._make_ring(RING_IPC)
+            if self.ring is None:
+                raise SystemExit(f"rank {rank}: no slab ring could be created: {lib.raw.lbm_last_error_string().decode()}")
+
+    def _make_ring(self, transport):
+        """collective: every rank tries; the ring is kept only if ALL ranks have one"""
+        lib, ctl = self.lib, self.ctl
+        ident = (ct.c_ubyte * 128)()
+        if ctl.rank == 0:
+            lib.ring_unique_id_ex(ident, transport)
+        ident = (ct.c_ubyte * 128).from_buffer_copy(ctl.bcast_bytes(bytes(ident)))
+        ring = ct.c_void_p()
+        rc = lib.raw.lbm_ring_create_ex(ct.byref(ring), ident, ctl.rank, ctl.world, ct.byref(self.geom), 1, transport)
+        ok = ctl.reduce([1.0 if rc == 0 else 0.0], "min")[0] > 0
+        if not ok:
+            if rc == 0:
+                lib.ring_destroy(ring)
+            elif ctl.rank == 0:
+                print(f"bench.py: lbm_ring_create_ex(transport {transport}): {lib.raw.lbm_last_error_string().decode()}", file=sys.stderr, flush=True)
+            return None
+        self.transport = transport
+        return ring
 
     def stream(self):
-        return ct.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        return ct.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
     def owned(self):
         return self.lat[self.cur][:, self.ghost:self.ghost + self.R, :]
 
     def load(self, f_pre):
         """f_pre [9,R,C]: pre-collision populations; resident state = collide(f_pre) + ghost fill"""
-        flat = pylbm.Geom(self.R, self.C, 0)
-        p = torch.empty_like(f_pre)
+        _ptr = self.pylbm._ptr
+        flat = self.pylbm.Geom(self.R, self.C, 0)
+        p = self.torch.empty_like(f_pre)
         self.lib.bgk_collide(_ptr(p), _ptr(f_pre), ct.byref(flat), None, ct.byref(self.prm), None, None, self.stream())
         self.owned().copy_(p)
         if self.ring:
@@ -145,6 +287,7 @@ class Box:
             self.lib.ring_join(self.ring, self.stream())
 
     def launch(self, n_steps):
+        _ptr = self.pylbm._ptr
         src, dst = self.lat[self.cur], self.lat[self.cur ^ 1]
         lib, g, bc, prm = self.lib, ct.byref(self.geom), ct.byref(self.bc), ct.byref(self.prm)
         if self.ring:
@@ -155,11 +298,13 @@ class Box:
             lib.bgk_stream_collide_xn(_ptr(dst), _ptr(src), g, bc, prm, n_steps, 0, self.R, self.stream())
         self.cur ^= 1
 
-    def selfcheck(self, D, world):
+    def selfcheck(self, D):
         """Two launches with the ring's default schedule (ghost = period x D rows: the first without an exchange) and
         the same two with an exchange on every launch, from the same state: owned rows must agree bit for bit on
         every rank.  The state is restored afterwards."""
+        torch, _ptr = self.torch, self.pylbm._ptr
         saved, cur0 = [b.clone() for b in self.buf], self.cur
+
         def restore():
             for b, s_ in zip(self.buf, saved):
                 b.copy_(s_)
@@ -175,13 +320,11 @@ class Box:
         self.launch(D)
         self.launch(D)
         torch.cuda.synchronize()
-        ok = torch.tensor([float(torch.equal(first, self.owned()))], device=self.dev)
+        ok = float(torch.equal(first, self.owned())) if self.lib.raw.lbm_ring_status(self.ring) == 0 else 0.0
         self.lib.set_tuning(b"ring_period", -1)
         restore()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        return bool(ok.item() > 0)
+        return self.ctl.reduce([ok], "min")[0] > 0
 
     def advance(self, n):
         """n time steps: n // D window launches, the remainder in single steps"""
@@ -199,51 +342,220 @@ class Box:
             self.ring = None
 
 
+# =====================================================================================================
+# HBM traffic by PMC counters: child runs of this script under rocprofv3 --pmc
+# =====================================================================================================
+def _pmc_run(counter, child_args, timeout_s):
+    """one `rocprofv3 --pmc <counter>` pass over `python bench.py --pmc-child ...`; returns the rows of its
+    counter_collection.csv (dispatch order) or raises"""
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise OSError("rocprofv3 not found")
+    d = tempfile.mkdtemp(prefix="lbm_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + child_args
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        rows = []
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            rows += [row for row in csv.DictReader(open(path)) if row["Counter_Name"] == counter]
+        if r.returncode != 0 or not rows:
+            raise OSError(f"{counter} pass failed (rc {r.returncode}, {len(rows)} rows): {r.stderr[-300:]}")
+        rows.sort(key=lambda row: int(row["Dispatch_Id"]))
+        return rows
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def pmc_traffic(argv_tail, kernel_tag="k_stream_collide_sw", timeout_s=150):
-    """HBM bytes per launch of the dominant kernel, measured NOW: two child runs of this script under
+    """HBM bytes per launch of the headline's kernel, measured NOW: two child runs of this script under
     `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE each in its own pass, as MI355X_MICROARCH.md prescribes;
     FETCH_SIZE x 2 = the gfx950 correction for wide coalesced reads, calibrated in profiles/).  Returns
     (fetch_bytes, write_bytes, note) or (None, None, reason).  The children only launch the kernel a few
     times (--pmc-child); nothing here is timed."""
-    import csv
-    import glob
-    import shutil
-    import subprocess
-    import tempfile
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, None, "rocprofv3 not found"
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        d = tempfile.mkdtemp(prefix="lbm_pmc_", dir="/tmp")
         try:
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
-                   os.path.abspath(__file__), "--pmc-child"] + argv_tail
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
-                               timeout=timeout_s)
-            vals = []
-            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(path)):
-                    if kernel_tag in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        vals.append(float(row["Counter_Value"]))
-            if r.returncode != 0 or len(vals) < 3:
-                return None, None, f"{counter} pass failed (rc {r.returncode}, {len(vals)} samples)"
+            rows = _pmc_run(counter, ["--pmc-child", "headline"] + argv_tail, timeout_s)
+            vals = [float(r["Counter_Value"]) for r in rows if kernel_tag in r["Kernel_Name"]]
+            if len(vals) < 3:
+                return None, None, f"{counter} pass: {len(vals)} samples"
             out[counter] = statistics.median(vals[2:]) * 1024.0     # KiB; the first launches warm the caches
         except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
-            return None, None, f"{counter} pass: {type(e).__name__}"
-        finally:
-            shutil.rmtree(d, ignore_errors=True)
+            return None, None, f"{counter} pass: {type(e).__name__}: {e}"
     return 2.0 * out["FETCH_SIZE"], out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE x 2: gfx950)"
 
 
-def timed_batches(box, steps, repeats, world, dev):
+def pmc_between_markers(which, timeout_s=240):
+    """HBM bytes of EVERYTHING a secondary workload launches between its two lbm_marker kernels (the child runs
+    set-up, marker, n steps, marker), per kernel name.  Returns {counter: {kernel_name: [sum_KiB, dispatches]}}."""
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        rows = _pmc_run(counter, ["--pmc-child", which], timeout_s)
+        marks = [i for i, r in enumerate(rows) if "k_lbm_marker" in r["Kernel_Name"]]
+        if len(marks) != 2:
+            raise OSError(f"{counter} pass of {which}: {len(marks)} markers in the trace")
+        per = {}
+        for r in rows[marks[0] + 1:marks[1]]:
+            e = per.setdefault(r["Kernel_Name"].split("(")[0][:120], [0.0, 0])
+            e[0] += float(r["Counter_Value"])
+            e[1] += 1
+        out[counter] = per
+    return out
+
+
+# =====================================================================================================
+# secondary workloads: BASELINE configs 3, 4, 5 on one GPU (SURVEY 8(d) C3-C5)
+# =====================================================================================================
+class Secondary:
+    """name, nodes, steps per launch group, algorithmic bytes per node and step, and a step(n) callable"""
+
+    def __init__(self, lib, dev, which):
+        import numpy as np
+        import torch
+        import pylbm
+        from pylbm import _ptr
+        self.lib, self.which, self.torch = lib, which, torch
+        if which == "kbc":      # config 3: ulbm_double_shear_flow.cpp:42-63 at 4096^2 (s2 = omega, nu = 1.70766666e-4)
+            R = C = 4096
+            self.unit = int(lib.raw.lbm_get_tuning(b"kbc_depth")) or 3
+            self.kernel = f"k_stream_collide_sw<KbcFastModel,{self.unit},2,nt>"
+            self.bytes_per_update, self.config = 144.0, "ulbm_double_shear_flow 4096x4096 KBC (entropic MRT), periodic"
+            self.sv = pylbm.Solver(lib, pylbm.MODEL_KBC, R, C, pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))
+            f = taylor_green(lib, torch, _ptr, R, C, 0, R, dev, U=0.02)
+            lib.solver_set_f_soa_dev(self.sv.h, _ptr(f))
+            self.step = lambda n: self.sv.step(n)
+        elif which == "cg":     # config 4: mrtcg_rayleigh_taylor.cpp:182-210 (init_rho_cosine) at 8192 x 2048
+            R, C = 8192, 2048
+            self.unit, self.kernel = 1, "k_cg_fused<16,32,4> (inner rectangle) + its frame instantiation"
+            self.bytes_per_update, self.config = 288.0, "mrtcg_rayleigh_taylor 8192x2048 colour-gradient two-phase MRT, gamma3 parameters"
+            prm = pylbm.cg_params()
+            rr = np.arange(R).reshape(-1, 1)
+            s = R / 2.0 - 0.1 * C * np.cos(2.0 * 3.141592 * np.arange(C) / C).reshape(1, -1)
+            rho_r, rho_b = 3.0 * (rr < s), 1.0 * (rr >= s)
+            d_rr, d_rb = (torch.from_numpy(x.astype(np.float64)).to(dev) for x in (rho_r, rho_b))
+            d_u = torch.zeros((2, R, C), dtype=torch.float64, device=dev)
+            f_r, f_b = (torch.empty((9, R, C), dtype=torch.float64, device=dev) for _ in range(2))
+            lib.cg_equilibrium(_ptr(f_r), _ptr(d_rr), _ptr(d_u), ct.byref(prm.red), R, C, ct.c_longlong(0), None)
+            lib.cg_equilibrium(_ptr(f_b), _ptr(d_rb), _ptr(d_u), ct.byref(prm.blue), R, C, ct.c_longlong(0), None)
+            torch.cuda.synchronize()
+            self.sv = pylbm.CgSolver(lib, R, C, prm)
+            self.sv.set_state(np.moveaxis(f_r.cpu().numpy(), 0, -1), np.moveaxis(f_b.cpu().numpy(), 0, -1), rho_r, rho_b, np.zeros((R, C, 2)))
+            self.step = lambda n: self.sv.step(n)
+        elif which == "ibm":    # config 5: cylinder_test.cpp:88-164, diameter 300 at rows / 4 (SURVEY 8(d) C5)
+            R, C = 16384, 4096
+            self.unit = int(lib.raw.lbm_get_tuning(b"ibm_depth")) or 5
+            self.kernel = "k_stream_collide_sw_walls<BgkModelT<0,1>,5,nt> (rows away from the cylinder) + forced box chain"
+            self.bytes_per_update, self.config = 144.0, "cylinder_test 16384x4096 BGK + immersed cylinder (d = 300, 942 markers), one block"
+            omega, u_in = 1.0 / 0.55, 0.04
+            m = int(round(np.pi * 300))
+            t = 2 * np.pi * np.arange(m) / m
+            x, y = R / 4.0 + 150 * np.cos(t), C / 2.0 + 150 * np.sin(t)
+            bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=pylbm.EDGE_SPECULAR,
+                          col_hi=pylbm.EDGE_SPECULAR, uw_r=u_in)
+            self.sv = pylbm.Solver(lib, pylbm.MODEL_BGK, R, C, pylbm.BgkParams(omega, 0, 1), bc=bc)
+            self.ib = pylbm.Ibm(lib, x, y, R, C)
+            self.sv.attach_ibm(self.ib)
+            u = torch.zeros((2, R, C), dtype=torch.float64, device=dev); u[0] = u_in
+            rho = torch.ones((R, C), dtype=torch.float64, device=dev)
+            f = torch.empty((9, R, C), dtype=torch.float64, device=dev)
+            lib.incomp_equilibrium(_ptr(f), _ptr(u), _ptr(rho), R, C, None)
+            lib.solver_set_f_soa_dev(self.sv.h, _ptr(f))
+            self.step = lambda n: self.sv.step(n)
+        else:
+            raise SystemExit(f"unknown secondary workload {which}")
+        self.R, self.C = R, C
+        torch.cuda.synchronize()
+        self.step(1)             # the driver's first iteration (collide-only launch / forcing on the initial state)
+        torch.cuda.synchronize()
+
+    def close(self):
+        self.sv.close()
+        if hasattr(self, "ib"):
+            self.ib.close()
+
+
+def secondary_child(lib, dev, which, groups=4):
+    """under rocprofv3 --pmc: set-up, marker, `groups` launch groups, marker"""
+    import torch
+    w = Secondary(lib, dev, which)
+    w.step(w.unit)                       # one group outside the bracket (first-touch effects)
+    torch.cuda.synchronize()
+    lib.marker(1, None)
+    torch.cuda.synchronize()
+    w.step(w.unit * groups)
+    torch.cuda.synchronize()
+    lib.marker(2, None)
+    torch.cuda.synchronize()
+    w.close()
+
+
+def run_secondary(lib, dev, which, a):
+    import torch
+    w = Secondary(lib, dev, which)
+    n = max(w.unit, (a.secondary_steps // w.unit) * w.unit)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < a.min_warm_s:
+        w.step(n)
+        torch.cuda.synchronize()
+    wall, devms = [], []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        w.step(n)
+        ev1.record()
+        torch.cuda.synchronize()
+        wall.append(time.perf_counter() - t0)
+        devms.append(ev0.elapsed_time(ev1))
+    w.close()
+    mid = sorted(range(5), key=lambda i: wall[i])[2]
+    dt, group_ms = wall[mid], devms[mid] / (n // w.unit)
+    nodes = w.R * w.C
+    alg = nodes * w.bytes_per_update * w.unit           # algorithmic bytes one launch group stands for
+    out = {"config": w.config, "value": round(nodes * n / dt / 1e6, 1), "unit": "MLUPS", "steps": n, "repeats": 5,
+           "ms_per_step": round(dt / n * 1e3, 4), "dtype": "f64", "kernel": w.kernel, "steps_per_launch": w.unit,
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                        "kernel_ms": round(group_ms, 4),
+                        "kernel_ms_is": "device time (HIP events on the launch stream) per launch group = all kernels of "
+                                        f"{w.unit} step(s), helper-stream launches included",
+                        "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": round(alg / (group_ms * 1e-3) / 1e9, 1),
+                        "algorithmic_multiple": round(alg / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if not a.no_pmc:
+        groups = 4
+        try:
+            pm = pmc_between_markers(which)
+            fetch = 2.0 * 1024.0 * sum(v[0] for v in pm["FETCH_SIZE"].values()) / groups
+            write = 1024.0 * sum(v[0] for v in pm["WRITE_SIZE"].values()) / groups
+            traffic = fetch + write
+            ach = traffic / (group_ms * 1e-3) / 1e9
+            roof = out["roofline"]
+            roof.update(traffic=traffic, achieved=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4),
+                        frac_of_copy_ceiling=round(ach / HBM_COPY_CEILING_GBS, 4),
+                        traffic_bytes_per_update=round(traffic / (nodes * w.unit), 2),
+                        traffic_over_algorithmic=round(traffic / alg, 3),
+                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run, every launch between two "
+                                       "marker kernels (FETCH_SIZE x 2: gfx950), per launch group",
+                        pmc={"fetch_bytes": fetch, "write_bytes": write,
+                             "per_kernel_KiB_per_group": {k: {"fetch_raw": round(v[0] / groups, 1), "launches": v[1] / groups,
+                                                              "write": round(pm["WRITE_SIZE"].get(k, [0.0, 0])[0] / groups, 1)}
+                                                          for k, v in pm["FETCH_SIZE"].items()}})
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+            out["roofline"]["traffic_source"] = f"PMC passes failed: {type(e).__name__}: {e}"
+    return out
+
+
+def timed_batches(box, steps, repeats, ctl):
     """`repeats` batches of exactly `steps` steps, each bracketed by barrier + synchronize; returns
     per-repeat (wall seconds, device ms between HIP events on the launch stream), MAX over ranks."""
+    torch = box.torch
     wall, devms, enq = [], [], []
     for _ in range(repeats):
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        ctl.barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -253,17 +565,13 @@ def timed_batches(box, steps, repeats, world, dev):
         enq.append(time.perf_counter() - t0)    # host time to ENQUEUE the batch (GPU-bound runs: well below wall)
         torch.cuda.synchronize()
         wall.append(time.perf_counter() - t0)
-        if world > 1:
-            dist.barrier()
+        ctl.barrier()
         torch.cuda.synchronize()
         devms.append(ev0.elapsed_time(ev1))
-    t = torch.tensor([wall, devms, enq], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return t[0].tolist(), t[1].tolist(), t[2].tolist()
+    return ctl.reduce(wall, "max"), ctl.reduce(devms, "max"), ctl.reduce(enq, "max")
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -286,26 +594,47 @@ def main():
     ap.add_argument("--edge-rows", type=int, default=32, help="rows at each slab end computed ahead of the halo exchange")
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not measure HBM traffic with rocprofv3 --pmc child runs (N = 1); report the committed profile's figure")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--ring-period", type=int, default=2,
                     help="slab ring: launches per halo exchange (ghost rows = period x D; 1: exchange every launch)")
     ap.add_argument("--force-halo", action="store_true",
-                    help="N=1 only: run the slab schedule (ghost rows, RCCL self send/recv every launch)")
-    a = ap.parse_args()
+                    help="N=1 only: run the slab schedule (ghost rows, self send/recv)")
+    ap.add_argument("--transport", choices=["rccl", "ipc"], default="rccl",
+                    help="slab ring transport: RCCL send/recv (default) or peer-mapped direct stores (hipIpc windows)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal: all N ranks on GPU 0 (peer-mapped transport, gloo control plane) -- checks the N-rank plumbing, not a scaling number")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks: seconds before the run is given up")
+    ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip configs 3 / 4 / 5 after the headline")
+    ap.add_argument("--secondary", default="kbc,cg,ibm", help="which secondary workloads (N = 1)")
+    ap.add_argument("--secondary-steps", type=int, default=30, help="time steps per timed batch of a secondary workload")
+    ap.add_argument("--secondary-only", action="store_true", help="skip the headline (profiling passes)")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.pmc_child:
+        sys.exit(self_launch(a, argv))
+
+    import torch
+    import pylbm
+    from pylbm import _ptr
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if a.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: either launch N ranks (torch.distributed.run) or unset WORLD_SIZE "
+                         "and let bench.py start them")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback on the product path)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible (one rank per GPU; "
+                         "--share-gpu puts every rank on GPU 0 for a rehearsal)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctl = Ctl(rank, world, dev, "gloo" if a.share_gpu else "nccl")
 
     lib = pylbm.Lib()
     lib.set_device(local_rank)
@@ -314,19 +643,27 @@ def main():
         lib.set_tuning(k.encode(), int(v))
     lib.set_tuning(b"sw_rows", a.sw_rows)
 
+    if a.pmc_child and a.pmc_child != "headline":
+        secondary_child(lib, dev, a.pmc_child)
+        return
+    if a.secondary_only:
+        out = {"secondary": [run_secondary(lib, dev, w, a) for w in a.secondary.split(",") if w]}
+        print(json.dumps(out), flush=True)
+        return
+
     R, C = a.rows, a.cols
-    box = Box(lib, a, rank, world, dev, with_ring=(world > 1 or a.force_halo))
+    transport = RING_IPC if (a.transport == "ipc" or a.share_gpu) else RING_RCCL
+    box = Box(lib, a, ctl, dev, with_ring=(world > 1 or a.force_halo), transport=transport)
     D = box.depth
-    f0 = taylor_green(lib, R, C, rank * R, world * R, dev)
+    f0 = taylor_green(lib, torch, _ptr, R, C, rank * R, world * R, dev)
     box.load(f0)
     del f0
 
     # -- slab ring: the one-exchange-per-`period`-launches schedule against one exchange per launch, here and now ----
-    # (N > 1 never ran on hardware before the driver's own scaling run: if the two ever differ on this machine, the
-    # timed run falls back to the plain schedule and says so)
+    # (if the two ever differ on this machine, the timed run falls back to the plain schedule and says so)
     ring_check = None
     if box.ring and box.period > 1 and not a.pmc_child:
-        ring_check = box.selfcheck(D, world)
+        ring_check = box.selfcheck(D)
         if "ring_period" in tune:
             lib.set_tuning(b"ring_period", int(tune["ring_period"]))
         if not ring_check:
@@ -349,25 +686,21 @@ def main():
         box.advance(4 * D)
         torch.cuda.synchronize()
         warm_steps += 4 * D
-        done = torch.tensor([float(time.perf_counter() - t_w >= a.min_warm_s)], device=dev)
-        if world > 1:
-            dist.all_reduce(done, op=dist.ReduceOp.MIN)   # all ranks leave the loop together
-        if done.item() > 0:
+        if ctl.reduce([float(time.perf_counter() - t_w >= a.min_warm_s)], "min")[0] > 0:   # all ranks leave the loop together
             break
 
     # -- timed region --------------------------------------------------------------------------
     repeats = a.repeats
     if repeats <= 0:
-        w1, _, _ = timed_batches(box, a.steps, 1, world, dev)        # pilot batch (also warm-up)
+        w1, _, _ = timed_batches(box, a.steps, 1, ctl)        # pilot batch (also warm-up)
         repeats = max(5, min(25, int(2.5 / max(w1[0], 1e-6))))
-    wall, devms, enq = timed_batches(box, a.steps, repeats, world, dev)
+    wall, devms, enq = timed_batches(box, a.steps, repeats, ctl)
     order = sorted(range(repeats), key=lambda i: wall[i])
     mid = order[repeats // 2]
     dt, dev_ms = wall[mid], devms[mid]
 
-    mass = box.owned().sum()
-    if world > 1:
-        dist.all_reduce(mass, op=dist.ReduceOp.SUM)
+    mass = ctl.reduce([float(box.owned().sum())], "sum")[0]
+    ring_status = int(ctl.reduce([float(lib.raw.lbm_ring_status(box.ring) != 0)], "max")[0]) if box.ring else 0
 
     # per-rank phase timing of one launch-step of the ring (outside the timed region)
     phases = None
@@ -382,15 +715,9 @@ def main():
             acc.append(list(out4))
         lib.ring_profile(box.ring, 0)
         med = [statistics.median(x[i] for x in acc) for i in range(4)]
-        t = torch.tensor(med, dtype=torch.float64, device=dev)
-        if world > 1:
-            g = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(g, t)
-        else:
-            g = [t]
         phases = [dict(rank=i, edge_rows_ms=round(float(x[0]), 4), exchange_ms=round(float(x[1]), 4),
                        interior_ms=round(float(x[2]), 4), launch_span_ms=round(float(x[3]), 4))
-                  for i, x in enumerate(g)]
+                  for i, x in enumerate(ctl.gather(med))]
 
     # informative second figure (N = 1 only, outside the timed region): the same launch schedule
     # with the collision in the reference's exact operation order (GPU bitwise == CPU oracle)
@@ -401,7 +728,7 @@ def main():
         d_ref = 4 if (D == 5 and not box.ring) else D   # this collision's best depth (132.6 k vs 127.1 k MLUPS at 5)
         box.depth = d_ref
         box.advance(4 * d_ref)
-        w2, _, _ = timed_batches(box, a.steps, 5, world, dev)
+        w2, _, _ = timed_batches(box, a.steps, 5, ctl)
         box.depth = D
         ref_order = {"value": round(R * C * a.steps / statistics.median(w2) / 1e6, 1), "unit": "MLUPS",
                      "steps": a.steps, "repeats": 5, "kernel": f"k_stream_collide_sw<BgkModelT<0,0>,{d_ref},4,nt>",
@@ -409,6 +736,7 @@ def main():
                      "note": "same kernel family, collision in the reference's operation order (bitwise equal to the CPU oracle)"}
         lib.set_tuning(b"bgk_fast", int(tune.get("bgk_fast", "-1")))
 
+    out = None
     if rank == 0:
         lups = R * C * world * a.steps / dt
         launches = box.launches(a.steps)
@@ -418,9 +746,6 @@ def main():
         # only meaningful when the batch holds that kernel alone
         kern_ms = dev_ms / launches if a.steps % D == 0 else None
         alg_bytes = R * C * BYTES_PER_LUP * D            # algorithmic bytes one launch stands for
-        # HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes) cannot
-        # be read from inside this process: the figure is the committed profile of this very kernel
-        # on this very lattice, else null
         traffic, traffic_src, valu = None, None, None
         live = None
         if world == 1 and not box.ring and D >= 2 and not a.no_pmc:
@@ -467,6 +792,7 @@ def main():
         if live:
             roof["pmc"] = live
             roof["minimum_bytes_per_launch"] = R * C * BYTES_PER_LUP     # one read + one write of the lattice
+        tname = {RING_RCCL: "RCCL send + recv", RING_IPC: "peer-mapped message (hipIpc window, direct stores)"}.get(box.transport)
         out = {
             "metric": "MLUPS (million lattice updates/sec), D2Q9 BGK periodic box, f64",
             "value": round(lups / 1e6, 1), "unit": "MLUPS", "n_gpus": world, "steps": a.steps,
@@ -479,11 +805,11 @@ def main():
                        "rows_per_gpu": R, "cols": C, "global_rows": R * world,
                        "plane_pad_doubles": box.plane - (R + 2 * box.ghost) * C,
                        "parallelism": f"slab{world}" if world > 1 else "single",
-                       "transport": (f"lbm_ring (csrc/capi_ring.hip): one RCCL send + recv per neighbour per {box.period} launch(es) on the "
+                       "transport": (f"lbm_ring (csrc/capi_ring.hip): one {tname} per neighbour per {box.period} launch(es) on the "
                                      "ring's own stream, interior rows on the caller's stream" if box.ring else None),
                        "halo": ("none" if not box.ghost else
                                 f"{9 * (box.ghost - 1) if box.ghost > 1 else 3} rows of C doubles per side per "
-                                f"{box.ghost} step(s) ({box.period} launch(es)) over RCCL send/recv")},
+                                f"{box.ghost} step(s) ({box.period} launch(es))")},
             "timing": {"protocol": f">= {a.min_warm_s} s of untimed launches after --warmup, then `repeats` batches of `steps` "
                                    "steps, each bracketed by barrier + synchronize, MAX over ranks; value = median batch",
                        "warm_steps_run": warm_steps,
@@ -493,18 +819,41 @@ def main():
                        "timed_region_s": round(sum(wall), 4)},
             "roofline": roof,
             "check": {"total_mass": float(mass), "expected_mass": float(R * C * world),
-                      **({"ring_schedules_agree_bitwise": ring_check} if ring_check is not None else {})},
+                      **({"ring_schedules_agree_bitwise": ring_check} if ring_check is not None else {}),
+                      **({"ring_status": "ok" if ring_status == 0 else "a bounded wait gave up"} if box.ring else {})},
         }
+        if a.share_gpu:
+            out["config"]["rehearsal"] = f"all {world} ranks on GPU 0: value is NOT a scaling number"
+        if box.transport_note:
+            out["config"]["transport_note"] = box.transport_note
         if phases:
             out["ring_phases"] = phases
         if ref_order:
             out["reference_order"] = ref_order
+    box.close()
+    del box
+    torch.cuda.empty_cache()
+    if rank == 0:
+        if world == 1 and not a.no_secondary:
+            sec = []
+            for w in [x for x in a.secondary.split(",") if x]:
+                try:
+                    sec.append(run_secondary(lib, dev, w, a))
+                except Exception as e:  # a secondary figure must never cost the headline its line
+                    sec.append({"config": w, "error": f"{type(e).__name__}: {e}"})
+                torch.cuda.empty_cache()
+            out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    box.close()
-    if world > 1:
-        dist.destroy_process_group()
+    ctl.close()
+    if box_failed(out, rank):
+        sys.exit(3)
+
+
+def box_failed(out, rank):
+    """a ring whose bounded waits gave up has produced void numbers: say so with the exit code too"""
+    return rank == 0 and out is not None and out.get("check", {}).get("ring_status", "ok") != "ok"
 
 
 if __name__ == "__main__":

@@ -632,6 +632,9 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * outermost strips / rows next to a wall row through the wall-carrying one, on a helper stream; 0: one
  * wall-carrying launch; same bits).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);
+/* an empty one-thread kernel ("k_lbm_marker") to cut a profiler trace at: measurement harnesses bracket the launches
+ * whose counters they sum with two of these */
+int lbm_marker(int tag, lbm_stream_t s);
 int lbm_get_tuning(const char* key);
 
 #ifdef __cplusplus
