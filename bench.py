@@ -388,12 +388,12 @@ def pmc_traffic(argv_tail, kernel_tag="k_stream_collide_sw", timeout_s=150):
     return 2.0 * out["FETCH_SIZE"], out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE x 2: gfx950)"
 
 
-def pmc_between_markers(which, timeout_s=240):
+def pmc_between_markers(which, extra_args=(), timeout_s=240):
     """HBM bytes of EVERYTHING a secondary workload launches between its two lbm_marker kernels (the child runs
     set-up, marker, n steps, marker), per kernel name.  Returns {counter: {kernel_name: [sum_KiB, dispatches]}}."""
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        rows = _pmc_run(counter, ["--pmc-child", which], timeout_s)
+        rows = _pmc_run(counter, ["--pmc-child", which] + list(extra_args), timeout_s)
         marks = [i for i, r in enumerate(rows) if "k_lbm_marker" in r["Kernel_Name"]]
         if len(marks) != 2:
             raise OSError(f"{counter} pass of {which}: {len(marks)} markers in the trace")
@@ -477,9 +477,14 @@ class Secondary:
             self.ib.close()
 
 
-def secondary_child(lib, dev, which, groups=4):
-    """under rocprofv3 --pmc: set-up, marker, `groups` launch groups, marker"""
+PMC_GROUPS = {"kbc": 4, "cg": 16, "ibm": 4}   # launch groups between the markers (cg: the LAST step of a call also writes
+                                              # the observable fields, 48 B per node: 1 step in 16 keeps that below 1 %)
+
+
+def secondary_child(lib, dev, which):
+    """under rocprofv3 --pmc: set-up, marker, PMC_GROUPS launch groups, marker"""
     import torch
+    groups = PMC_GROUPS[which]
     w = Secondary(lib, dev, which)
     w.step(w.unit)                       # one group outside the bracket (first-touch effects)
     torch.cuda.synchronize()
@@ -525,9 +530,9 @@ def run_secondary(lib, dev, which, a):
                         "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": round(alg / (group_ms * 1e-3) / 1e9, 1),
                         "algorithmic_multiple": round(alg / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
     if not a.no_pmc:
-        groups = 4
+        groups = PMC_GROUPS[which]
         try:
-            pm = pmc_between_markers(which)
+            pm = pmc_between_markers(which, [x for kv in a.tune for x in ("--tune", kv)])
             fetch = 2.0 * 1024.0 * sum(v[0] for v in pm["FETCH_SIZE"].values()) / groups
             write = 1024.0 * sum(v[0] for v in pm["WRITE_SIZE"].values()) / groups
             traffic = fetch + write

@@ -123,7 +123,29 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 2>), dim3(frame), dim3(TR * TC), 0, fs, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
     LBM_CHECK_LAUNCH();
   }
-  if (const int sw = tuning("cg_strip2", 0)) {  // the inner rectangle through a register-ring strip kernel
+  const int sw4 = tuning("cg_strip2", 0);
+  // 21 / 22: the lockstep block kernel (k_cg_strip4, 4 / 8 waves per block); needs line-aligned rows and planes
+  if ((sw4 == 21 || sw4 == 22) && g.C % 16 == 0 && g.plane % 16 == 0 && rc.ic0 * TC >= 2 * CG_S4_EDGE) {
+    const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
+    const int Wv = sw4 == 21 ? 4 : 8, S = 64 * Wv - 2 * CG_S4_EDGE;
+    const int win0 = (ca - CG_S4_EDGE) / 16 * 16;  // line-aligned window start; lane CG_S4_EDGE = first possible output
+    const int bstrips = (cb - (win0 + CG_S4_EDGE) + S - 1) / S;
+    const void* kfn = sw4 == 21 ? (psi ? (const void*)k_cg_strip4<4, true> : (const void*)k_cg_strip4<4, false>)
+                                : (psi ? (const void*)k_cg_strip4<8, true> : (const void*)k_cg_strip4<8, false>);
+    int rpc = tuning("cg_rows2", 0);
+    if (rpc <= 0) {
+      const long slots = sw_wave_slots(kfn, 64 * Wv);
+      rpc = slots > 0 ? sw_pick_rows(rb - ra, bstrips * Wv, 3, slots) : 64;
+    }
+    if (rpc > rb - ra) rpc = rb - ra;
+    const int chunks = (rb - ra + rpc - 1) / rpc;
+#define LBM_CG_S4(WV)                                                                                              \
+    if (psi) LBM_KLAUNCH((k_cg_strip4<WV, true>), dim3(bstrips * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, bstrips, win0); \
+    else LBM_KLAUNCH((k_cg_strip4<WV, false>), dim3(bstrips * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, bstrips, win0);
+    if (sw4 == 21) { LBM_CG_S4(4) } else { LBM_CG_S4(8) }
+#undef LBM_CG_S4
+  } else
+  if (const int sw = (sw4 == 21 || sw4 == 22) ? 0 : sw4) {  // the inner rectangle through a register-ring strip kernel
     // 1, 2, 4: k_cg_strip2 (one wave per SIMD) with that many waves per workgroup; 11, 12: k_cg_strip3 (colour sums
     // of the ring rows in LDS, two waves per SIMD) with 1 / 2 waves per workgroup
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;

@@ -818,4 +818,146 @@ __global__ __launch_bounds__(64 * WAVES, 2) void k_cg_strip3(
   }
 }
 
+// ---- fourth generation: a WORKGROUP of W waves walks down a 64 W-column window in lockstep ------------------------
+// What the round-3 calibration (scripts/calib/fetch_calib.hip, profiles/r03_fetch_calib.txt) showed: the L2 fetches whole
+// 128-BYTE LINES, one request per line a wave's load touches, and neighbouring waves share a line only when they sit in
+// one workgroup at the same time.  A private 64-column window with 56 outputs that starts 32 bytes off a line boundary
+// (k_cg_strip2 / 3) therefore pays 5 lines for 3.5 lines of output on every one of its 18 streams -- the 1.38x read
+// amplification PMC measured.  Here
+//   * the block's window starts on a line boundary (a multiple of 16 columns) and is 64 W columns wide; only its first and
+//     last 8 lanes are ring-only, so a block reads 4 W lines per row and stream for 4 W - 1 lines of output (W = 4: 1.067x),
+//     and the +-1-column pulls of a wave land in lines its neighbours in the block load in the same iteration;
+//   * psi, Qx, Qy of a row go into ONE ring shared by the block (6 slots: the slot a fast wave writes next is never one a
+//     slow wave still reads), so all lanes but the 16 at the block's edges produce output -- one workgroup barrier per row;
+//   * the colour-summed populations wait in a wave-private ring of TWO rows (the row just reduced stays in registers until
+//     the row two behind it has been collided out of the slot it takes): 18.4 KB of LDS per wave, 8 waves per CU.
+// Per-node arithmetic = the tile kernel's: identical bits.
+constexpr int CG_S4_EDGE = 8;
+
+template <int W, int K, bool WITH_FIELDS>
+__device__ __forceinline__ void cg_strip4_iter(
+    double (&rn)[3][6], double (&raw_r)[Q], double (&raw_b)[Q], double (*s_ft)[Q][64], double (*s_psi)[64 * W],
+    double (*s_qx)[64 * W], double (*s_qy)[64 * W], double* __restrict__ pn_r, double* __restrict__ pn_b,
+    const double* __restrict__ in_r, const double* __restrict__ in_b, const Geom& g, const CgFast& cf,
+    const MacroIdx& mi, int i, int n_iter, int R0, int lane, int gl, int cl, int c, bool lane_out,
+    double* __restrict__ rho_r_out, double* __restrict__ rho_b_out, double* __restrict__ u_out,
+    double* __restrict__ psi_out, double* __restrict__ snu_out) {
+#pragma clang fp contract(on)
+  if (i >= n_iter) return;  // uniform over the block: all its waves walk the same chunk
+  double ft[Q];
+  {
+    // reduce the arrived row R0 - 2 + i (== cg_node<true>)
+    const double (&fr)[Q] = raw_r;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ft[q] = raw_b[q];
+    const double rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
+    const double rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) ft[q] += fr[q];
+    const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
+    const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
+    const double irt = 1.0 / (rr + rb);
+    const double ux = (jx + 0.5 * cf.Gr) * irt, uy = (jy + 0.5 * cf.Gc) * irt;
+    const double a = rr * cf.inv_rho0[0], b = rb * cf.inv_rho0[1];
+    const double psi = (a - b) / (a + b);
+    const double qcs = cf.qc[0] * rr + cf.qc[1] * rb;
+    const int slot = i % 6;
+    s_psi[slot][gl] = psi;
+    s_qx[slot][gl] = qcs * ux;
+    s_qy[slot][gl] = qcs * uy;
+    rn[K][0] = rr; rn[K][1] = rb; rn[K][2] = ux; rn[K][3] = uy; rn[K][4] = irt; rn[K][5] = psi;
+  }
+  if (i + 1 < n_iter) {  // the next row into the registers just freed; in flight during the collision below
+    const long o = g.at(R0 - 1 + i, cl);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
+      raw_r[q] = in_r[off];
+      raw_b[q] = in_b[off];
+    }
+  }
+  __syncthreads();  // the row's psi, Qx, Qy of every wave of the block are in the ring
+  if (i >= 4 && lane_out) {
+    constexpr int KC = (K + 1) % 3;
+    const int r = R0 + i - 4;
+    const int s0 = (i - 4) % 6, s1 = (i - 3) % 6, s3 = (i - 1) % 6, s4 = i % 6;
+    constexpr double k = 1.0 / 5040.0;
+    constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
+    constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
+    const int l0 = gl - 2;  // columns c - 2 .. c + 2 sit at [l0 .. l0 + 4]
+    double gx = 0.0, dxqx = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < 5; ++j) {  // == cg_ddrow
+      gx += a0[j] * (s_psi[s4][l0 + j] - s_psi[s0][l0 + j]);
+      gx += a1[j] * (s_psi[s3][l0 + j] - s_psi[s1][l0 + j]);
+      dxqx += a0[j] * (s_qx[s4][l0 + j] - s_qx[s0][l0 + j]);
+      dxqx += a1[j] * (s_qx[s3][l0 + j] - s_qx[s1][l0 + j]);
+    }
+    double gy = 0.0, dyqy = 0.0;
+#pragma unroll 1
+    for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
+      const int sl = (i - 4 + ii) % 6;
+      gy += a0[ii] * (s_psi[sl][l0 + 4] - s_psi[sl][l0]);
+      gy += a1[ii] * (s_psi[sl][l0 + 3] - s_psi[sl][l0 + 1]);
+      dyqy += a0[ii] * (s_qy[sl][l0 + 4] - s_qy[sl][l0]);
+      dyqy += a1[ii] * (s_qy[sl][l0 + 3] - s_qy[sl][l0 + 1]);
+    }
+    double fc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) fc[q] = s_ft[i & 1][q][lane];  // reduced two iterations ago
+    CgNode me;
+    me.rr = rn[KC][0]; me.rb = rn[KC][1]; me.ux = rn[KC][2]; me.uy = rn[KC][3]; me.irt = rn[KC][4]; me.psi = rn[KC][5];
+    me.qx = 0.0; me.qy = 0.0;
+    cg_collide_store<WITH_FIELDS>(fc, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out, rho_b_out,
+                                  u_out, psi_out, snu_out);
+  }
+  // ... and only now does this iteration's row take that slot (same wave, same lanes: program order suffices)
+#pragma unroll
+  for (int q = 0; q < Q; ++q) s_ft[i & 1][q][lane] = ft[q];
+}
+
+template <int W, bool WITH_FIELDS>
+__global__ __launch_bounds__(64 * W, 2) void k_cg_strip4(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
+    int rows_per_chunk, int bstrips, int win0) {
+  __shared__ double ring[3][6][64 * W];  // [field][slot][block lane]
+  __shared__ double ftr[W][2][Q][64];    // [wave][ring row][population][lane]
+  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, gl = threadIdx.x;
+  constexpr int S = 64 * W - 2 * CG_S4_EDGE;  // output columns per block (a multiple of 16: windows stay line-aligned)
+  const int bs = blockIdx.x % bstrips, chunk = blockIdx.x / bstrips;
+  const int R0 = row_begin + chunk * rows_per_chunk;
+  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
+  const int c = win0 + bs * S + gl;  // this lane's column
+  const bool lane_out = gl >= CG_S4_EDGE && gl < 64 * W - CG_S4_EDGE && c >= col_begin && c < col_end;
+  // loads stay inside the lattice (lanes beyond the rectangle's ring feed nothing that is stored)
+  const int cl = c < 1 ? 1 : (c > g.C - 2 ? g.C - 2 : c);
+  double(*s_psi)[64 * W] = ring[0];
+  double(*s_qx)[64 * W] = ring[1];
+  double(*s_qy)[64 * W] = ring[2];
+  double(*s_ft)[Q][64] = ftr[wib];
+  double rn[3][6], raw_r[Q], raw_b[Q];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) rn[a][q] = 1.0;
+  {
+    const long o = g.at(R0 - 2, cl);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
+      raw_r[q] = in_r[off];
+      raw_b[q] = in_b[off];
+    }
+  }
+  const int n_iter = (R1 - R0) + 4;
+  for (int i = 0; i < n_iter; i += 3) {
+    cg_strip4_iter<W, 0, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i, n_iter, R0, lane, gl, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
+    cg_strip4_iter<W, 1, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 1, n_iter, R0, lane, gl, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
+    cg_strip4_iter<W, 2, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 2, n_iter, R0, lane, gl, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
+  }
+}
+
 }  // namespace lbm

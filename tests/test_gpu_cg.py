@@ -282,7 +282,7 @@ def test_cg_fused_two_slabs_equal_single_block(lib, oracle):
         assert relerr(got, want[key]) < 1e-11, (key, relerr(got, want[key]))
 
 
-@pytest.mark.parametrize("R,C", [(64, 32), (256, 200), (130, 61)])
+@pytest.mark.parametrize("R,C", [(64, 32), (256, 200), (130, 61), (200, 544), (130, 1040)])
 def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
     """The two one-launch kernels -- LDS tile (default) and column-strip sliding window
     (tuning cg_strip = 1 / 2 / 4), the tile kernel with and without its inner / frame split (cg_split) -- share the per-node arithmetic (FMA per source expression): identical
@@ -307,7 +307,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         # the general boundary gather
         # strip >= 10: the inner rectangle through the register-ring strip kernel (cg_strip2 = strip - 10 waves
         # per workgroup, cg_rows2 rows per chunk), the frame through the tile kernel
-        for strip, rows in ((0, 64), (0, 0), (1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33), (21, 40), (22, 9)):
+        for strip, rows in ((0, 64), (0, 0), (1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33), (21, 40), (22, 9),
+                            (31, 40), (31, 7), (32, 9), (32, 64)):   # 31 / 32: the lockstep block kernel (cg_strip2 = 21 / 22)
             lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
             lib.set_tuning(b"cg_strip2", strip - 10 if strip >= 10 else 0)
             lib.set_tuning(b"cg_rows2", rows if rows else 64)
