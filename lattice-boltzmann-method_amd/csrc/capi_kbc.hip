@@ -156,7 +156,11 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
     return LBM_OK;
   }
 #define LBM_KBC_SW_TAIL tuning("sw_xcd", 0)
-  if (depth == 2) LBM_KBC_SW(KbcFastModel, 2, 2, true)
+  // "sw_ldsring" (default 1): the ring of the 2- / 3-step window in wave-private LDS instead of registers (d2q9.hpp LDSR)
+  const bool ldsr = tuning("sw_ldsring", 1) != 0;
+  if (depth == 2 && ldsr) LBM_KBC_SW(KbcFastModel, 2, 2, true, false, false, true)
+  else if (depth == 3 && ldsr) LBM_KBC_SW(KbcFastModel, 3, 2, true, false, false, true)
+  else if (depth == 2) LBM_KBC_SW(KbcFastModel, 2, 2, true)
   else if (depth == 3) LBM_KBC_SW(KbcFastModel, 3, 2, true)
   else LBM_KBC_SW(KbcFastModel, 4, 2, true)
 #undef LBM_KBC_SW_TAIL

@@ -610,12 +610,25 @@ __device__ __forceinline__ double lane_from_next(double v) {  // lane i <- lane 
 #endif
 }
 
-template <class Model, int D, int K, bool NT_STORE, bool HAS_BC = false>
+// LDSR: the ring lives in wave-private LDS instead of registers -- a level's row is written once and the next level
+// pulls its 9 populations with ds_read_b64 whose +-1-lane offsets ARE the column shift (no DPP moves), and nothing of
+// the ring competes for the 256 architectural VGPRs (the register ring of a VALU-heavy model lives partly in AGPRs:
+// two v_accvgpr moves per double and use).  Of a row computed in iteration i the next level reads the c_x = -1
+// populations (q = 3, 6, 7) in iteration i, the c_x = 0 ones (0, 2, 4) in i + 1 and the c_x = +1 ones (1, 5, 8) in
+// i + 2; pulling the old rows BEFORE publishing the new one, that is 1 + 1 + 2 slots of 3 populations per level --
+// 12 doubles per lane instead of 27: 6.3 KB per wave and level, so that a 3-step window runs TWO waves per SIMD.
+// Same values, same bits.
+constexpr int SW_LDS_LANES = 66;  // 1 + lane + 1: the +-1-lane reads of lanes 0 / 63 stay inside (they feed invalid lanes only)
+__host__ __device__ constexpr int sw_lds_level_doubles() { return 12 * SW_LDS_LANES; }
+__host__ __device__ constexpr int sw_lds_ring_doubles(int D) { return (D > 1 ? D - 1 : 1) * sw_lds_level_doubles(); }
+__host__ __device__ constexpr int sw_grp_pos(int q) { return (q == 3 || q == 0 || q == 1) ? 0 : ((q == 6 || q == 2 || q == 5) ? 1 : 2); }
+
+template <class Model, int D, int K, bool NT_STORE, bool HAS_BC = false, bool LDSR = false>
 __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3][Q], double (&cur)[Q],
                                              double* __restrict__ pn, const double* __restrict__ po,
                                              const Geom& g, const Model& m, int i, int rbase, int R0,
                                              int R1, int c_load, const int (&cols)[3], bool lane_ok,
-                                             int c_out, const Bc& bc = Bc{}, int c_raw = 0) {
+                                             int c_out, const Bc& bc = Bc{}, int c_raw = 0, double* lds = nullptr, int lane = 0) {
   // ---- prefetch level-1 inputs of the NEXT iteration -----------------------------------------
   double nxt[Q];
   {
@@ -656,6 +669,33 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
     // publish level l-1's row of this iteration, then gather level l's row from the ring:
     // cx = -1 pops from the row just computed (slot K), cx = 0 from the previous iteration's row
     // (slot K+2), cx = +1 from the one before (slot K+1); cy = +-1 via the neighbouring lanes.
+    if constexpr (LDSR) {
+      double* lv = lds + (l - 2) * sw_lds_level_doubles();
+      double* slotA = lv;                                               // c_x = -1 populations of the newest row
+      double* slotB = lv + 3 * SW_LDS_LANES;                            // c_x = 0 populations of the row before
+      double* slotC = lv + (6 + 3 * (i & 1)) * SW_LDS_LANES;            // c_x = +1 populations of the row two before (same parity as i)
+      double fn[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {  // 1. the old rows, before this iteration's row takes their slots
+        if (icx(q) == 0) fn[q] = slotB[sw_grp_pos(q) * SW_LDS_LANES + lane + 1 - icy(q)];
+        else if (icx(q) == 1) fn[q] = slotC[sw_grp_pos(q) * SW_LDS_LANES + lane + 1 - icy(q)];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {  // 2. publish level l-1's row of this iteration
+        double* dst = icx(q) == -1 ? slotA : (icx(q) == 0 ? slotB : slotC);
+        dst[sw_grp_pos(q) * SW_LDS_LANES + lane + 1] = f[q];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int q = 0; q < Q; ++q)    // 3. the c_x = -1 populations come from the row just published
+        if (icx(q) == -1) fn[q] = slotA[sw_grp_pos(q) * SW_LDS_LANES + lane + 1 - icy(q)];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) f[q] = fn[q];
+    } else {
 #pragma unroll
     for (int q = 0; q < Q; ++q) ring[l - 2][K][q] = f[q];
 #pragma unroll
@@ -666,7 +706,8 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
       else if (icy(q) == -1) v = lane_from_next(v);  // from column c+1
       f[q] = v;
     }
-    if (HAS_BC) {  // level l's row; its own level-(l-1) populations sit in the ring's c_x = 0 slot
+    }
+    if (HAS_BC && !LDSR) {  // level l's row; its own level-(l-1) populations sit in the ring's c_x = 0 slot
       int rl = rbase + i - (l - 1);
       if (rows_wrap) rl = rl < 0 ? rl + g.R : (rl >= g.R ? rl - g.R : rl);
       const bool wall_row = (rl == 0 && bc_is_wall(bc.row_lo)) || (rl == g.R - 1 && bc_is_wall(bc.row_hi));
@@ -765,10 +806,12 @@ template <class M>
 struct sw_full_strips<M, std::void_t<decltype(M::kFullStrips)>> : std::bool_constant<M::kFullStrips> {};
 __host__ __device__ constexpr int sw_waves_per_simd(int D) { return D <= 2 ? 4 : (D == 3 ? 3 : (D <= 5 ? 2 : 1)); }
 // one wavefront's walk down its strip chunk: `wave` = its index among the strips x chunks of this part of the launch
-template <class Model, int D, bool NT_STORE, bool HAS_BC, bool PF2>
+template <class Model, int D, bool NT_STORE, bool HAS_BC, bool PF2, bool LDSR = false>
 __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const double* __restrict__ po, const Geom& g,
                                              const Model& m, int row_begin, int row_end, int rows_per_chunk, int strips,
-                                             int wave, int lane, const Bc& bc, int strip0, int chunk_stride) {
+                                             int wave, int lane, const Bc& bc, int strip0, int chunk_stride,
+                                             double* lds = nullptr) {
+  static_assert(!(LDSR && (HAS_BC || PF2)), "the LDS ring exists for the plain window only");
   constexpr int W = sw_strip_width(D, sw_full_strips<Model>::value);  // output columns per wave
   const int strip = strip0 + wave % strips, chunk = wave / strips;  // strips = those of this launch, from strip0 on
   // chunk_stride > rows_per_chunk: the chunks are row ranges apart from each other (both edge-row
@@ -838,15 +881,21 @@ __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const doub
   // periodic columns the WRAPPED one -- a lane left of column 0 holds a real node of a wall ROW and needs its fix-ups
   // like any other (row walls + periodic columns: the corner lanes fed garbage into the valid columns before)
   const int c_bc = walled_cols ? c_raw : c;
+  if constexpr (LDSR) {  // warm-up garbage must be finite numbers here too
+    for (int k = lane; k < sw_lds_ring_doubles(D); k += 64) lds[k] = 1.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
   for (int i = 0; i < n_iter; i += 3) {
-    sw_iteration<Model, D, 0, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc);
-    sw_iteration<Model, D, 1, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc);
-    sw_iteration<Model, D, 2, NT_STORE, HAS_BC>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc);
+    sw_iteration<Model, D, 0, NT_STORE, HAS_BC, LDSR>(ring, cur, pn, po, g, m, i, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc, lds, lane);
+    sw_iteration<Model, D, 1, NT_STORE, HAS_BC, LDSR>(ring, cur, pn, po, g, m, i + 1, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc, lds, lane);
+    sw_iteration<Model, D, 2, NT_STORE, HAS_BC, LDSR>(ring, cur, pn, po, g, m, i + 2, rbase, R0, R1, c, cols, lane_ok, c, bc, c_bc, lds, lane);
   }
 }
 
-template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)) void k_stream_collide_sw(
+template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false, bool LDSR = false>
+__global__ __launch_bounds__(64 * WAVES, (LDSR ? 2 : (WAVES == 4 ? sw_waves_per_simd(D) : 1))) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
     int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0,
     int chunk_stride = 0) {
@@ -858,9 +907,17 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 4 ? sw_waves_per_simd(D) : 1)
     const int x = blk % 8, mth = blk / 8, win = 8 * xcd_group;
     if ((mth / xcd_group + 1) * win <= (int)gridDim.x) blk = (mth / xcd_group) * win + x * xcd_group + mth % xcd_group;
   }
-  const int wave = blk * WAVES + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // readfirstlane: the wave index is uniform, and only then do the row indices and the 18 row base addresses of an
+  // iteration live in scalar registers (KBC window: ~6 % fewer VALU instructions; the kernel is VALU-bound)
+  const int wave = blk * WAVES + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wave >= n_waves) return;
-  sw_wave_body<Model, D, NT_STORE, HAS_BC, PF2>(pn, po, g, m, row_begin, row_end, rows_per_chunk, strips, wave, lane, bc, strip0, chunk_stride);
+  if constexpr (LDSR) {
+    __shared__ double lring[WAVES * sw_lds_ring_doubles(D)];
+    sw_wave_body<Model, D, NT_STORE, HAS_BC, PF2, true>(pn, po, g, m, row_begin, row_end, rows_per_chunk, strips, wave, lane, bc, strip0, chunk_stride,
+                                                        lring + (threadIdx.x >> 6) * sw_lds_ring_doubles(D));
+  } else {
+    sw_wave_body<Model, D, NT_STORE, HAS_BC, PF2>(pn, po, g, m, row_begin, row_end, rows_per_chunk, strips, wave, lane, bc, strip0, chunk_stride);
+  }
 }
 
 // Wall-bounded launch in ONE dispatch: the few waves of the frame (outermost strips, rows next to a wall row) run the
@@ -878,7 +935,7 @@ struct SwParts {
 template <class Model, int D, bool NT_STORE>
 __global__ __launch_bounds__(128, 1) void k_stream_collide_sw_walls(double* __restrict__ pn, const double* __restrict__ po,
                                                                     Geom g, Model m, Bc bc, SwParts parts) {
-  const int wave = blockIdx.x * 2 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * 2 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (wave >= parts.n_waves) return;
   if (wave < parts.n_frame_waves) {
     int k = 0;

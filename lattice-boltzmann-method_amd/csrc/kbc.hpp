@@ -137,14 +137,19 @@ struct KbcModel {
 //    feq_q = rho psi_cx(ux) psi_cy(uy);  the relaxed populations reuse the same two vectors:
 //        f' = f - s2 (S - cs2 rho G) - gamma s2 (H - cs4 rho V8);
 //  * the conserved central moments T0, T1, T2 (zero up to rounding when the moments are the
-//    populations' own) are not carried through the back-transform;
-//  * 1 / feq_q = (1/rho)(1/psi_cx)(1/psi_cy): 7 reciprocals (v_rcp_f64 + one Newton step) and one
-//    division instead of 12 IEEE divisions.  FMA contraction is on.
-// ~330 f64 operations per node instead of ~940; agreement with the reference-order model to
-// rounding (tests/test_gpu_kbc.py states the tolerance).
+//    populations' own) are not carried through the back-transform.
+// Round 3 (the kernel is VALU-bound at one wave per SIMD, so only the instruction count moves it:
+// 276 f64 operations + 8 v_rcp_f64 per collision before, profiles/r03_kbc_*):
+//  * every vector is carried WITHOUT its lattice weight w_q = 1, 1/2, 1/4 (S = w S~, H = w H~, G = w G~,
+//    feq = w rho D_i D_j): the 25 scalings by 1/2 and 1/4 disappear into three constants of the final update;
+//  * delta_s~ = S~ - (rho D_i) D_j and delta_h~ likewise are single FMAs: feq is never formed;
+//  * gamma's two sums (eval_gamma :138-148) are sums over the 3 x 3 velocity grid of  X_i Y_j ds~ dh~  with
+//    X_i = w_i / D_i: 1/rho cancels between numerator and denominator, and the six reciprocals come out of ONE
+//    v_rcp_f64 of the product of all six D (batch inversion) -- 3 reciprocals per node instead of 8.
+// Agreement with the reference-order model to rounding (tests/test_gpu_kbc.py states the tolerance).
 struct KbcFastModel {
-  double s2, is2;  // is2 = 1 / s2, one IEEE division on the host instead of one per node
-  __host__ __device__ explicit KbcFastModel(double s) : s2(s), is2(1.0 / s) {}
+  double s2, is2, hs2, qs2;  // is2 = 1 / s2 (one IEEE division on the host instead of one per node); s2 / 2, s2 / 4
+  __host__ __device__ explicit KbcFastModel(double s) : s2(s), is2(1.0 / s), hs2(0.5 * s), qs2(0.25 * s) {}
   static constexpr bool kFullStrips = true;  // VALU-bound in the sliding window: d2q9.hpp sw_strip_width
 
   __device__ __forceinline__ static double rcp(double x) {
@@ -175,62 +180,57 @@ struct KbcFastModel {
     const double C7 = (m12 - ux * m02) - 2.0 * uy * C5;
     const double C8 = ((m22 - 2.0 * (uy * m21 + ux * m12)) + (uy2 * m20 + ux2 * m02)) +
                       (4.0 * uxy * m11 - 3.0 * (jx * ux) * uy2);
-    // S = M^-1 N^-1 (0,0,0,C3,C4,C5,0,0,0), C3 = k20 + k02, C4 = k20 - k02
+    // S~ = M^-1 N^-1 (0,0,0,C3,C4,C5,0,0,0) / w, C3 = k20 + k02, C4 = k20 - k02
     const double i6s = k20 * uy + 2.0 * C5 * ux, i7s = k02 * ux + 2.0 * C5 * uy;
     const double i8s = (k02 * ux2 + k20 * uy2) + 4.0 * C5 * uxy;
-    double S[Q], H[Q];
-    S[0] = i8s - (k20 + k02);
-    S[1] = 0.5 * (k20 - (i7s + i8s));
-    S[3] = 0.5 * (k20 + (i7s - i8s));
-    S[2] = 0.5 * (k02 - (i6s + i8s));
-    S[4] = 0.5 * (k02 + (i6s - i8s));
-    S[5] = 0.25 * ((C5 + i8s) + (i6s + i7s));
-    S[6] = 0.25 * ((i8s - C5) + (i6s - i7s));
-    S[7] = 0.25 * ((C5 + i8s) - (i6s + i7s));
-    S[8] = 0.25 * ((i8s - C5) - (i6s - i7s));
-    // H = M^-1 N^-1 (0,...,0,C6,C7,C8)
-    const double i8h = 2.0 * (C6 * uy + C7 * ux) + C8;
-    H[0] = i8h;
-    H[1] = -0.5 * (C7 + i8h);
-    H[3] = 0.5 * (C7 - i8h);
-    H[2] = -0.5 * (C6 + i8h);
-    H[4] = 0.5 * (C6 - i8h);
-    H[5] = 0.25 * (i8h + (C6 + C7));
-    H[6] = 0.25 * (i8h + (C6 - C7));
-    H[7] = 0.25 * (i8h - (C6 + C7));
-    H[8] = 0.25 * (i8h - (C6 - C7));
-    // product-form equilibrium and its reciprocal
-    const double px0 = (1.0 - cs2) - ux2, pxp = 0.5 * ((ux2 + cs2) + ux), pxm = 0.5 * ((ux2 + cs2) - ux);
-    const double py0 = (1.0 - cs2) - uy2, pyp = 0.5 * ((uy2 + cs2) + uy), pym = 0.5 * ((uy2 + cs2) - uy);
-    const double rx0 = rho * px0, rxp = rho * pxp, rxm = rho * pxm;       // rho folded into the x factor
-    const double ix0 = irho * rcp(px0), ixp = irho * rcp(pxp), ixm = irho * rcp(pxm);
-    const double iy0 = rcp(py0), iyp = rcp(pyp), iym = rcp(pym);
-    const double fe[Q] = {rx0 * py0, rxp * py0, rx0 * pyp, rxm * py0, rx0 * pym,
-                          rxp * pyp, rxm * pyp, rxm * pym, rxp * pym};
-    const double ie[Q] = {ix0 * iy0, ixp * iy0, ix0 * iyp, ixm * iy0, ix0 * iym,
-                          ixp * iyp, ixm * iyp, ixm * iym, ixp * iym};
-    // delta_h rows 5-8 as written in the reference: "ux2 + uy" where the algebra has ux2 * uy (Q8)
-    const double qa = -0.25 * rho * ((ux2 + uy) - ux2 * uy), qb = -0.25 * rho * ((uy - ux2) + ux2 * uy);
-    const double quirk[Q] = {0.0, 0.0, 0.0, 0.0, 0.0, qa, qa, qb, qb};
-    double num = 0.0, den = 0.0;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const double ds = S[q] - fe[q], dh = (H[q] - fe[q]) + quirk[q];
-      const double t = dh * ie[q];
-      num += ds * t;
-      den += dh * t;
-    }
-    const double gamma = is2 - (1.0 - is2) * (num * rcp(den));  // eval_gamma :138-148
-    // relaxed populations: f - s2 (S - cs2 rho G) - gamma s2 (H - cs4 rho V8)
-    const double g2 = ux2 + uy2, cr = cs2 * rho, gs = gamma * s2, hr = cs4 * rho;
-    const double G[Q] = {g2 - 2.0,
-                         -0.5 * ((g2 - 1.0) + ux), -0.5 * ((g2 - 1.0) + uy),
-                         -0.5 * ((g2 - 1.0) - ux), -0.5 * ((g2 - 1.0) - uy),
-                         0.25 * (g2 + (ux + uy)), 0.25 * (g2 - (ux - uy)),
-                         0.25 * (g2 - (ux + uy)), 0.25 * (g2 + (ux - uy))};
-    constexpr double V8[Q] = {1.0, -0.5, -0.5, -0.5, -0.5, 0.25, 0.25, 0.25, 0.25};
-#pragma unroll
-    for (int q = 0; q < Q; ++q) f[q] = (f[q] - s2 * (S[q] - cr * G[q])) - gs * (H[q] - hr * V8[q]);
+    const double c5p = C5 + i8s, c5m = i8s - C5, s67 = i6s + i7s, d67 = i6s - i7s;
+    const double S0 = i8s - (k20 + k02);
+    const double S1 = k20 - (i7s + i8s), S3 = k20 + (i7s - i8s);
+    const double S2 = k02 - (i6s + i8s), S4 = k02 + (i6s - i8s);
+    const double S5 = c5p + s67, S6 = c5m + d67, S7 = c5p - s67, S8 = c5m - d67;
+    // H~ = M^-1 N^-1 (0,...,0,C6,C7,C8) / w
+    const double H0 = 2.0 * (C6 * uy + C7 * ux) + C8;
+    const double csum = C6 + C7, cdif = C6 - C7;
+    const double H1 = -(C7 + H0), H3 = C7 - H0, H2 = -(C6 + H0), H4 = C6 - H0;
+    const double H5 = H0 + csum, H6 = H0 + cdif, H7 = H0 - csum, H8 = H0 - cdif;
+    // product-form equilibrium feq_q = w_q rho D_i D_j: D_0 = 2/3 - u^2, D_+- = (u^2 + 1/3) +- u
+    const double bx = ux2 + cs2, by = uy2 + cs2;
+    const double Dx0 = (1.0 - cs2) - ux2, Dxp = bx + ux, Dxm = bx - ux;
+    const double Dy0 = (1.0 - cs2) - uy2, Dyp = by + uy, Dym = by - uy;
+    const double rx0 = rho * Dx0, rxp = rho * Dxp, rxm = rho * Dxm;
+    // delta_s~, delta_h~ (rows 5-8 of delta_h as written in the reference: "ux2 + uy" where the algebra has ux2 * uy, Q8)
+    const double qa = rho * ((ux2 + uy) - ux2 * uy), qb = rho * ((uy - ux2) + ux2 * uy);
+    const double ds0 = S0 - rx0 * Dy0, ds1 = S1 - rxp * Dy0, ds2 = S2 - rx0 * Dyp, ds3 = S3 - rxm * Dy0, ds4 = S4 - rx0 * Dym;
+    const double ds5 = S5 - rxp * Dyp, ds6 = S6 - rxm * Dyp, ds7 = S7 - rxm * Dym, ds8 = S8 - rxp * Dym;
+    const double dh0 = H0 - rx0 * Dy0, dh1 = H1 - rxp * Dy0, dh2 = H2 - rx0 * Dyp, dh3 = H3 - rxm * Dy0, dh4 = H4 - rx0 * Dym;
+    const double dh5 = (H5 - rxp * Dyp) - qa, dh6 = (H6 - rxm * Dyp) - qa, dh7 = (H7 - rxm * Dym) - qb, dh8 = (H8 - rxp * Dym) - qb;
+    // X_i = w_i / D_i, Y_j = w_j / D_j from ONE reciprocal of the product of the six D
+    const double ax = Dxp * Dxm, px = Dx0 * ax, ay = Dyp * Dym, py = Dy0 * ay;
+    const double Rall = rcp(px * py);
+    const double Rx = Rall * py, Ry = Rall * px;
+    const double X0 = Rx * ax, hx = (0.5 * Rx) * Dx0, Xp = hx * Dxm, Xm = hx * Dxp;
+    const double Y0 = Ry * ay, hy = (0.5 * Ry) * Dy0, Yp = hy * Dym, Ym = hy * Dyp;
+    // eval_gamma :138-148: num / den = sum X_i Y_j ds~ dh~ / sum X_i Y_j dh~^2 (1 / rho cancels)
+    const double t0 = dh0 * Y0, t1 = dh1 * Y0, t3 = dh3 * Y0;
+    const double t2 = dh2 * Yp, t5 = dh5 * Yp, t6 = dh6 * Yp;
+    const double t4 = dh4 * Ym, t8 = dh8 * Ym, t7 = dh7 * Ym;
+    const double n0 = (ds0 * t0 + ds2 * t2) + ds4 * t4, e0 = (dh0 * t0 + dh2 * t2) + dh4 * t4;
+    const double np = (ds1 * t1 + ds5 * t5) + ds8 * t8, ep = (dh1 * t1 + dh5 * t5) + dh8 * t8;
+    const double nm = (ds3 * t3 + ds6 * t6) + ds7 * t7, em = (dh3 * t3 + dh6 * t6) + dh7 * t7;
+    const double num = (X0 * n0 + Xp * np) + Xm * nm, den = (X0 * e0 + Xp * ep) + Xm * em;
+    const double gamma = is2 - (1.0 - is2) * (num * rcp(den));
+    // relaxed populations: f - s2 w (S~ - cs2 rho G~) - gamma s2 w (H~ - cs4 rho V8~), V8~ = (1, -1 x 4, 1 x 4)
+    const double g2 = ux2 + uy2, gm = g2 - 1.0, us = ux + uy, ud = ux - uy;
+    const double cr = cs2 * rho, hr = cs4 * rho, gs = gamma * s2, hgs = gamma * hs2, qgs = gamma * qs2;
+    f[0] = (f[0] - s2 * (S0 - cr * (g2 - 2.0))) - gs * (H0 - hr);
+    f[1] = (f[1] - hs2 * (S1 + cr * (gm + ux))) - hgs * (H1 + hr);
+    f[2] = (f[2] - hs2 * (S2 + cr * (gm + uy))) - hgs * (H2 + hr);
+    f[3] = (f[3] - hs2 * (S3 + cr * (gm - ux))) - hgs * (H3 + hr);
+    f[4] = (f[4] - hs2 * (S4 + cr * (gm - uy))) - hgs * (H4 + hr);
+    f[5] = (f[5] - qs2 * (S5 - cr * (g2 + us))) - qgs * (H5 - hr);
+    f[6] = (f[6] - qs2 * (S6 - cr * (g2 - ud))) - qgs * (H6 - hr);
+    f[7] = (f[7] - qs2 * (S7 - cr * (g2 - us))) - qgs * (H7 - hr);
+    f[8] = (f[8] - qs2 * (S8 - cr * (g2 + ud))) - qgs * (H8 - hr);
   }
 };
 
