@@ -477,6 +477,15 @@ int lbm_slab_ibm_create(lbm_slab_ibm** out, const lbm_geom* slab, int slab_row0,
                         const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth, const double* x,
                         const double* y, int n_markers, int m_max, double guo_a, double guo_b);
 int lbm_slab_ibm_destroy(lbm_slab_ibm* sl);
+/* slab heights for a chain of n_slabs slabs over rows_global rows such that all slabs finish a block together: the slab
+ * that holds the forced band pays its chain of `depth` forced single steps on top of its rows, so it gets the band and few
+ * other rows, and the band stays inside ONE slab (host arithmetic only; usable without a GPU).  Per-block cost model:
+ * slabs without band rows far_us_per_row x rows, the owner owner_us + owner_us_per_row x rows; costs = {far_us_per_row,
+ * owner_us, owner_us_per_row} or NULL = the table measured on MI355X (scaled with cols and depth).  x: GLOBAL marker rows.
+ * rows_out[n_slabs] sums to rows_global; *predicted_us (may be NULL) = the slowest slab's block time under the model.
+ * Every rank of a chain calls it with the same arguments and takes rows_out[rank]. */
+int lbm_slab_ibm_plan_rows(int* rows_out, int n_slabs, int rows_global, int cols, int depth, const double* x,
+                           int n_markers, const double* costs, double* predicted_us);
 /* owner: this slab runs the band chain; straddle_*: the band's valid rows reach into that neighbour
  * (a co-owner); [b0, b1): global band rows.  Any output may be NULL. */
 int lbm_slab_ibm_info(const lbm_slab_ibm* sl, int* owner, int* straddle_prev, int* straddle_next, int* b0, int* b1);

@@ -173,6 +173,70 @@ int lbm_slab_ibm_create(lbm_slab_ibm** out, const lbm_geom* slab, int slab_row0,
   return LBM_OK;
 }
 
+// Slab heights for a chain of n slabs: a chain runs at its slowest slab's pace, and the slab that
+// carries the forced band pays its chain of D forced single steps (latency-bound, ~76 us per step beside the window launch)
+// whatever its height -- so it gets the band and little else, and the band is kept INSIDE one slab (a seam through the band
+// makes two co-owners run the whole chain).  Cost model per block, linear in the rows (MI355X, profiles/r02_cylinder_*,
+// r03_cylinder_planned*): slabs without band rows  far_us_per_row x rows;  the owner  owner_us + owner_us_per_row x rows
+// (its far rows run beside the chain).  costs = {far_us_per_row, owner_us, owner_us_per_row} or NULL for the built-in table
+// (scaled with the columns and the depth).  Exhaustive search over the owner's slab index, first row and height (multiples of
+// 4 rows); the slabs before / after the owner share their rows equally.  Falls back to equal heights when the band fits no
+// single slab.  rows_out[n_slabs]; *predicted_us (may be NULL): block time of the slowest slab under the model.
+int lbm_slab_ibm_plan_rows(int* rows_out, int n_slabs, int rows_global, int cols, int depth, const double* x, int n_markers,
+                           const double* costs, double* predicted_us) {
+  LBM_REQUIRE(rows_out && x && n_slabs >= 1 && n_markers > 0 && cols > 0 && depth >= 2 && depth <= 5,
+              "lbm_slab_ibm_plan_rows: bad argument");
+  const int N = n_slabs, Rg = rows_global, D = depth, hmin_any = 4 * D + 8;
+  LBM_REQUIRE(Rg >= N * hmin_any, "lbm_slab_ibm_plan_rows: %d rows cannot be cut into %d slabs of at least %d", Rg, N, hmin_any);
+  const double far = costs ? costs[0] : 0.1855 * (cols / 4096.0) * (D / 5.0);
+  const double oc0 = costs ? costs[1] : 76.0 * D, oc1 = costs ? costs[2] : 0.30 * far;
+  auto equal = [&](int total, int k, int* out) {  // k heights that differ by at most one row
+    for (int i = 0; i < k; ++i) out[i] = total / k + (i < total % k ? 1 : 0);
+  };
+  long q0 = 1L << 30, q1 = 0;  // ROI rows, ibm.cpp:124-153
+  for (int i = 0; i < n_markers; ++i) {
+    const long fx = (long)std::floor(x[i]);
+    q0 = std::min(q0, fx - 2);
+    q1 = std::max(q1, fx + 3);
+  }
+  const int v0 = (int)q0 - D, v1 = (int)q1 + D;  // the band's valid rows [v0, v1): what one slab must hold
+  double best = 1e300;
+  int bk = -1, br0 = 0, bh = 0;
+  if (N == 1) {
+    rows_out[0] = Rg;
+    if (predicted_us) *predicted_us = oc0 + oc1 * Rg;
+    return LBM_OK;
+  }
+  const int h_lo = std::max((v1 - v0 + 3) / 4 * 4, (hmin_any + 3) / 4 * 4);
+  for (int k = 0; k < N; ++k) {
+    const int nb = k, na = N - 1 - k;
+    for (int h = h_lo; h <= Rg - (N - 1) * hmin_any; h += 4) {
+      const double t_own = oc0 + oc1 * h;
+      if (t_own >= best) break;  // taller owners only get slower
+      for (int r0 = std::max(0, v1 - h); r0 <= v0; ++r0) {
+        if (r0 % 4 && r0 != v1 - h) continue;
+        const int before = r0, after = Rg - r0 - h;
+        if (after < 0) break;
+        if ((nb == 0) != (before == 0) || (na == 0) != (after == 0)) continue;
+        if ((nb && before < nb * hmin_any) || (na && after < na * hmin_any)) continue;
+        const double tb = nb ? far * ((before + nb - 1) / nb) : 0.0, ta = na ? far * ((after + na - 1) / na) : 0.0;
+        const double t = std::max(t_own, std::max(tb, ta));
+        if (t < best) best = t, bk = k, br0 = r0, bh = h;
+      }
+    }
+  }
+  if (bk < 0) {  // the band fits no single slab under these constraints: equal heights (two slabs will share the band)
+    equal(Rg, N, rows_out);
+    if (predicted_us) *predicted_us = oc0 + far * ((Rg + N - 1) / N);
+    return LBM_OK;
+  }
+  if (bk > 0) equal(br0, bk, rows_out);
+  rows_out[bk] = bh;
+  if (bk < N - 1) equal(Rg - br0 - bh, N - 1 - bk, rows_out + bk + 1);
+  if (predicted_us) *predicted_us = best;
+  return LBM_OK;
+}
+
 int lbm_slab_ibm_info(const lbm_slab_ibm* sl, int* owner, int* straddle_prev, int* straddle_next, int* b0, int* b1) {
   LBM_REQUIRE(sl, "lbm_slab_ibm_info: NULL argument");
   if (owner) *owner = sl->owner;

@@ -15,8 +15,11 @@
 //                      (messages moved by device copies; per-slab time per block reported; --check 1
 //                      compares with the single-block run bit for bit -- the 8 x 2048 x 4096 layout of
 //                      BASELINE config 5 fits one MI355X several times over)
-//                      --slab-rows r0,r1,...: one height per slab instead of N x --rows -- a chain runs at its
-//                      slowest slab's pace, and the slabs that carry the forced band should own fewer rows
+//   slab heights (all modes): the domain has N x --rows rows; by default the LIBRARY cuts it (lbm_slab_ibm_plan_rows: the
+//                      slab that holds the forced band pays its chain on top of its rows, so it gets the band and little
+//                      else, and all slabs finish a block together); --uniform 1: N equal slabs (the cylinder then
+//                      straddles a seam of the BASELINE layout); --slab-rows r0,r1,...: heights by hand;
+//                      --costs far_us_per_row,owner_us,owner_us_per_row: the planner's cost model instead of its table
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_cylinder --id-file /tmp/x ...
 //
 // tau = 0.55 (parameters.toml), u_in = 0.04 (SURVEY 8d allows a smaller u for the benchmark), markers
@@ -33,9 +36,10 @@ namespace {
 
 struct Args {
   int rows = 2048, cols = 4096, steps = 50, warmup = 5, edge_rows = 32, check = 0, diameter = 300;
-  int depth = 5, centre_row = -1, emulate = 0;
+  int depth = 5, centre_row = -1, emulate = 0, uniform = 0;
   std::string id_file;
-  std::string slab_rows;  // --emulate: comma-separated slab heights (default: N x --rows)
+  std::string slab_rows;  // comma-separated slab heights (default: planned by the library)
+  std::string costs;      // far_us_per_row,owner_us,owner_us_per_row for the planner
 };
 const double kTau = 0.55, kUin = 0.04, kGuoA = 1.0 / 3.0, kGuoB = 1.0 / 9.0;  // cylinder_test.cpp:66-67
 
@@ -50,6 +54,42 @@ void cylinder_markers(int Rg, int C, int centre_row, int diameter, std::vector<d
     x[i] = cx + rad * std::cos(t);
     y[i] = cy + rad * std::sin(t);
   }
+}
+
+std::vector<double> parse_list(const std::string& s) {
+  std::vector<double> v;
+  size_t pos = 0;
+  while (pos < s.size()) {
+    const size_t end = s.find(',', pos);
+    v.push_back(std::atof(s.substr(pos, end == std::string::npos ? std::string::npos : end - pos).c_str()));
+    pos = end == std::string::npos ? s.size() : end + 1;
+  }
+  return v;
+}
+
+// heights of the N slabs of a domain of N x --rows rows: by hand, equal, or planned by the library (the default)
+std::vector<int> slab_heights(const Args& a, int N, const std::vector<double>& mx, std::string& how, double& predicted_us) {
+  const int Rg = a.rows * N;
+  std::vector<int> rows(N, a.rows);
+  predicted_us = 0;
+  if (!a.slab_rows.empty()) {
+    const std::vector<double> v = parse_list(a.slab_rows);
+    if ((int)v.size() != N) throw std::runtime_error("--slab-rows needs one height per slab");
+    for (int r = 0; r < N; ++r) {
+      rows[r] = (int)v[r];
+      if (rows[r] <= 0) throw std::runtime_error("--slab-rows needs one positive height per slab");
+    }
+    how = "given";
+  } else if (a.uniform || N == 1) {
+    how = "uniform";
+  } else {
+    const std::vector<double> c = parse_list(a.costs);
+    if (!c.empty() && c.size() != 3) throw std::runtime_error("--costs needs far_us_per_row,owner_us,owner_us_per_row");
+    check(lbm_slab_ibm_plan_rows(rows.data(), N, Rg, a.cols, a.depth, mx.data(), (int)mx.size(), c.empty() ? nullptr : c.data(), &predicted_us),
+          "lbm_slab_ibm_plan_rows");
+    how = "planned (lbm_slab_ibm_plan_rows)";
+  }
+  return rows;
 }
 
 lbm_bc global_bc() {
@@ -87,8 +127,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   check(lbm_set_device(local_rank), "lbm_set_device");
   const bool rehearse = false;
   const int vr = rank, vw = world;
-  const int D = a.depth, R = a.rows, C = a.cols, Rg = R * vw, G = D;
-  lbm_geom g{R, C, G, 0};
+  const int D = a.depth, C = a.cols, Rg = a.rows * vw, G = D;
   lbm_bgk_params prm{};
   prm.omega = 1.0 / kTau;
   prm.incompressible = 0;
@@ -97,8 +136,16 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
 
   std::vector<double> mx, my;
   cylinder_markers(Rg, C, a.centre_row, a.diameter, mx, my);
+  std::string how;
+  double predicted_us = 0;
+  const std::vector<int> heights = slab_heights(a, vw, mx, how, predicted_us);  // the same on every rank
+  std::vector<int> row0s(vw, 0);
+  for (int r = 1; r < vw; ++r) row0s[r] = row0s[r - 1] + heights[r - 1];
+  if (row0s[vw - 1] + heights[vw - 1] != Rg) throw std::runtime_error("slab heights do not add up to the domain");
+  const int R = heights[vr];
+  lbm_geom g{R, C, G, 0};
   lbm_slab_ibm* sl = nullptr;
-  check(lbm_slab_ibm_create(&sl, &g, vr * R, Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB),
+  check(lbm_slab_ibm_create(&sl, &g, row0s[vr], Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB),
         "lbm_slab_ibm_create");
   int owner = 0, sp = 0, sn = 0, b0 = 0, b1 = 0;
   check(lbm_slab_ibm_info(sl, &owner, &sp, &sn, &b0, &b1), "lbm_slab_ibm_info");
@@ -139,7 +186,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   }
   int first_owner = -1;  // every rank can tell who owns band rows: valid rows [b0 + D, b1 - D)
   for (int r = 0; r < vw && first_owner < 0; ++r)
-    if (b0 + D < (r + 1) * R && b1 - D > r * R) first_owner = r;
+    if (b0 + D < row0s[r] + heights[r] && b1 - D > row0s[r]) first_owner = r;
 
   int bad = 0;
   if (a.check && !rehearse) {
@@ -169,8 +216,10 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
         check(lbm_solver_sync(sv), "sync");
         check(lbm_stream_sync(nullptr), "sync");
         for (int r = 0; r < world; ++r) {
-          wait_file(a.id_file + ".f" + std::to_string(r), own.data(), own.size() * 8);
-          if (std::memcmp(&own[(size_t)q * n], &want[(size_t)r * n], n * 8) != 0) ++bad;
+          const size_t nr = (size_t)heights[r] * C;
+          std::vector<double> theirs((size_t)9 * nr);
+          wait_file(a.id_file + ".f" + std::to_string(r), theirs.data(), theirs.size() * 8);
+          if (std::memcmp(&theirs[(size_t)q * nr], &want[(size_t)row0s[r] * C], nr * 8) != 0) ++bad;
         }
       }
       double Fw[2], Fo[2];
@@ -186,12 +235,12 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
     double Fo[2] = {0, 0};
     if (owner) std::memcpy(Fo, Fs, sizeof Fo);
     else if (!rehearse && first_owner >= 0 && first_owner < world) wait_file(a.id_file + ".g" + std::to_string(first_owner), Fo, sizeof Fo);
-    std::printf("{\"driver\": \"slab_ring_cylinder\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, \"global_rows\": %d, "
+    std::printf("{\"driver\": \"slab_ring_cylinder\", \"n_gpus\": %d, \"rows_of_rank_0\": %d, \"cols\": %d, \"global_rows\": %d, "
                 "\"markers\": %d, \"band_rows\": [%d, %d], \"first_owner_rank\": %d, \"this_rank\": {\"rank\": %d, \"owner\": %d, "
                 "\"straddle_prev\": %d, \"straddle_next\": %d}, \"steps_per_block\": %d, \"steps\": %d, \"ms_per_step\": %.4f, "
                 "\"mlups_per_gpu\": %.1f, \"mlups\": %.1f, \"Fs\": [%.17g, %.17g], \"transport\": \"rccl send/recv (C++ ring)%s\"%s}\n",
                 world, R, C, Rg, (int)mx.size(), b0, b1, first_owner, vr, owner, sp, sn, D, steps, 1e3 * tmax / steps,
-                (double)R * C * steps / tmax / 1e6, (double)R * C * world * steps / tmax / 1e6, Fo[0], Fo[1],
+                (double)Rg / world * C * steps / tmax / 1e6, (double)Rg * C * steps / tmax / 1e6, Fo[0], Fo[1],
                 rehearse ? ", one GPU rehearsing one slab with self send/recv" : "",
                 a.check && !rehearse ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
     std::fflush(stdout);
@@ -208,24 +257,23 @@ int run_emulated(const Args& a, int N) {
   const int D = a.depth, C = a.cols, G = D;
   // slab heights: uniform, or as listed (a load-balanced decomposition gives the slabs that share the forced band
   // fewer rows: their block carries the band's chain on top of their far rows)
-  std::vector<int> rows(N, a.rows), row0(N, 0);
-  if (!a.slab_rows.empty()) {
-    size_t pos = 0;
-    for (int r = 0; r < N; ++r) {
-      const size_t end = a.slab_rows.find(',', pos);
-      rows[r] = std::atoi(a.slab_rows.substr(pos, end == std::string::npos ? std::string::npos : end - pos).c_str());
-      if (rows[r] <= 0) throw std::runtime_error("--slab-rows needs one positive height per slab");
-      pos = end == std::string::npos ? a.slab_rows.size() : end + 1;
-    }
+  std::vector<int> row0(N, 0);
+  std::vector<double> mx, my;
+  {
+    int total = 0;
+    if (!a.slab_rows.empty()) for (double v : parse_list(a.slab_rows)) total += (int)v;
+    else total = a.rows * N;
+    cylinder_markers(total, C, a.centre_row, a.diameter, mx, my);
   }
+  std::string how;
+  double predicted_us = 0;
+  std::vector<int> rows = slab_heights(a, N, mx, how, predicted_us);
   int Rg = 0;
   for (int r = 0; r < N; ++r) row0[r] = Rg, Rg += rows[r];
   lbm_bgk_params prm{};
   prm.omega = 1.0 / kTau;
   prm.delta_form = 1;
   lbm_bc bc = global_bc();
-  std::vector<double> mx, my;
-  cylinder_markers(Rg, C, a.centre_row, a.diameter, mx, my);
   struct Slab {
     int R = 0, row0 = 0;
     size_t n = 0, plane = 0;
@@ -355,10 +403,11 @@ int run_emulated(const Args& a, int N) {
   }
   double slowest = 0;
   for (int r = 0; r < N; ++r) slowest = std::max(slowest, S[r].ms / nb);
-  std::printf("{\"driver\": \"slab_ring_cylinder\", \"mode\": \"emulated chain on one GPU\", \"slabs\": %d, \"rows_per_slab\": %d, "
+  std::printf("{\"driver\": \"slab_ring_cylinder\", \"mode\": \"emulated chain on one GPU\", \"slabs\": %d, \"slab_heights\": \"%s\", "
+              "\"planner_predicted_ms_per_block\": %.4f, "
               "\"cols\": %d, \"global_rows\": %d, \"markers\": %d, \"band_rows\": [%d, %d], \"steps_per_block\": %d, \"steps\": %d, "
               "\"slowest_slab_ms_per_block\": %.4f, \"chain_mlups_at_the_slowest_slabs_pace\": %.1f, \"per_slab\": [",
-              N, a.slab_rows.empty() ? a.rows : 0, C, Rg, (int)mx.size(), b0, b1, D, steps, slowest, (double)Rg * C * D / slowest / 1e3);
+              N, how.c_str(), predicted_us / 1e3, C, Rg, (int)mx.size(), b0, b1, D, steps, slowest, (double)Rg * C * D / slowest / 1e3);
   for (int r = 0; r < N; ++r)
     std::printf("%s{\"slab\": %d, \"rows\": %d, \"owner\": %d, \"straddle_prev\": %d, \"straddle_next\": %d, \"ms_per_block\": %.4f, \"mlups\": %.1f}",
                 r ? ", " : "", r, S[r].R, S[r].owner, S[r].sp, S[r].sn, S[r].ms / nb, (double)S[r].R * C * D / (S[r].ms / nb) / 1e3);
@@ -384,6 +433,8 @@ int main(int argc, char** argv) {
   a.depth = std::atoi(arg_value(argc, argv, "--depth", "5").c_str());
   a.centre_row = std::atoi(arg_value(argc, argv, "--centre-row", "-1").c_str());
   a.slab_rows = arg_value(argc, argv, "--slab-rows", "");
+  a.costs = arg_value(argc, argv, "--costs", "");
+  a.uniform = std::atoi(arg_value(argc, argv, "--uniform", "0").c_str());
   a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.diameter = std::atoi(arg_value(argc, argv, "--diameter", "300").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());

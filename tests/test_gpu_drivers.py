@@ -193,13 +193,31 @@ def test_slab_ring_cylinder_emulated_chain_with_the_cylinder_on_a_seam(tmp_path)
     == the single block bit for bit (populations of every slab, surface force of both co-owners)"""
     import json
     exe = os.path.join(BIN, "slab_ring_cylinder")
-    r = subprocess.run([exe, "--emulate", "4", "--rows", "96", "--cols", "160", "--diameter", "30", "--steps", "15",
+    r = subprocess.run([exe, "--emulate", "4", "--uniform", "1", "--rows", "96", "--cols", "160", "--diameter", "30", "--steps", "15",
                         "--warmup", "5", "--check", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["check"] == "bitwise equal to one block"
     roles = [(s["owner"], s["straddle_prev"], s["straddle_next"]) for s in line["per_slab"]]
     assert roles == [(1, 0, 1), (1, 1, 0), (0, 0, 0), (0, 0, 0)], roles
+
+
+def test_slab_ring_cylinder_emulated_chain_with_planned_slab_heights(tmp_path):
+    """the default: the LIBRARY cuts the domain (lbm_slab_ibm_plan_rows) -- the forced band lands inside ONE short slab,
+    nobody straddles; == the single block bit for bit"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_cylinder")
+    r = subprocess.run([exe, "--emulate", "4", "--rows", "96", "--cols", "160", "--diameter", "30", "--steps", "15",
+                        "--warmup", "5", "--check", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block" and line["slab_heights"].startswith("planned")
+    heights = [s["rows"] for s in line["per_slab"]]
+    assert sum(heights) == 384 and min(heights) >= 28
+    roles = [(s["owner"], s["straddle_prev"], s["straddle_next"]) for s in line["per_slab"]]
+    assert sum(o for o, _, _ in roles) == 1 and all(sp == 0 and sn == 0 for _, sp, sn in roles), roles
+    owner = [s for s in line["per_slab"] if s["owner"]][0]
+    assert owner["rows"] == min(heights)          # the band's slab is the short one
 
 
 def test_slab_ring_cylinder_emulated_chain_with_unequal_slab_heights(tmp_path):
