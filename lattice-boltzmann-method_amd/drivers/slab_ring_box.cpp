@@ -86,7 +86,7 @@ double* make_slab(const Args& a, int R, int row0, int Rg, const lbm_geom& g, con
 }
 
 int run_rank(const Args& a, int rank, int world, int local_rank) {
-  check(lbm_set_device(local_rank), "lbm_set_device");
+  check(lbm_set_device(std::getenv("LBM_ONE_GPU") ? 0 : local_rank), "lbm_set_device");
   const int R = a.rows, C = a.cols, D = a.depth, Rg = R * world;
   // ghost = period x D rows: lbm_ring_bgk_step / _kbc_step exchange once per `period` launches
   const int G = D * (D < 2 ? 1 : a.period);
@@ -210,6 +210,11 @@ int main(int argc, char** argv) {
   if (a.kbc && a.depth > 4) a.depth = 3;
   a.id_file = arg_value(argc, argv, "--id-file", "/tmp/lbm_ring_id." + std::to_string((long)getpid()));
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
+  // --transport rccl|ipc: what carries the ring's messages (lbm_ring_unique_id / lbm_ring_create follow the environment);
+  // --one-gpu 1: every rank on GPU 0 (with ipc: N real ranks on one device, which RCCL refuses)
+  const std::string transport = arg_value(argc, argv, "--transport", "");
+  if (!transport.empty()) setenv("LBM_RING_TRANSPORT", transport.c_str(), 1);
+  if (std::atoi(arg_value(argc, argv, "--one-gpu", "0").c_str())) setenv("LBM_ONE_GPU", "1", 1);
   try {
     if (spawn > 0) {
       cleanup_ring_files(a.id_file, spawn);  // a stale id file of a killed run must not be picked up

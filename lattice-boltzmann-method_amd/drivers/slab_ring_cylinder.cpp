@@ -124,7 +124,7 @@ double* uniform_inflow(int R, int C, int G) {
 }
 
 int run_rank(const Args& a, int rank, int world, int local_rank) {
-  check(lbm_set_device(local_rank), "lbm_set_device");
+  check(lbm_set_device(std::getenv("LBM_ONE_GPU") ? 0 : local_rank), "lbm_set_device");
   const bool rehearse = false;
   const int vr = rank, vw = world;
   const int D = a.depth, C = a.cols, Rg = a.rows * vw, G = D;
@@ -440,6 +440,11 @@ int main(int argc, char** argv) {
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
   a.id_file = arg_value(argc, argv, "--id-file", "/tmp/lbm_ring_id." + std::to_string((long)getpid()));
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
+  // --transport rccl|ipc: what carries the ring's messages (lbm_ring_unique_id / lbm_ring_create follow the environment);
+  // --one-gpu 1: every rank on GPU 0 (with ipc: N real ranks on one device, which RCCL refuses)
+  const std::string transport = arg_value(argc, argv, "--transport", "");
+  if (!transport.empty()) setenv("LBM_RING_TRANSPORT", transport.c_str(), 1);
+  if (std::atoi(arg_value(argc, argv, "--one-gpu", "0").c_str())) setenv("LBM_ONE_GPU", "1", 1);
   try {
     if (a.emulate > 0) return run_emulated(a, a.emulate);
     if (spawn > 0) {

@@ -6,6 +6,11 @@
 //
 //   slab_ring_rt --spawn N [--rows R_per_gpu] [--cols C] [--steps K] [--warmup W] [--edge-rows E]
 //                [--check 1]   (rank 0 recomputes the whole domain as one block: small sizes only)
+//                [--transport rccl|ipc] [--one-gpu 1]  (ipc + one-gpu: N real ranks sharing GPU 0 through the
+//                peer-mapped transport -- RCCL refuses two ranks on one device)
+//   slab_ring_rt --emulate N ...   ONE process / one GPU playing all N slabs of the chain in turn (edge rows, interior
+//                rows, pack -> device copy -> unpack of the 3 ghost rows of both colours, per-slab time by HIP events;
+//                --check 1: bitwise against the single block) -- BASELINE config 4 = --emulate 4 --rows 2048 --cols 2048
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_rt --id-file /tmp/x ...     under any launcher
 //
 // Parameters: [red]/[blue] of mrtcg-rayleigh-taylor-gamma3.toml, sigma = 0.1, g = 6.25e-6
@@ -20,7 +25,7 @@
 namespace {
 
 struct Args {
-  int rows = 2048, cols = 2048, steps = 50, warmup = 5, edge_rows = 16, check = 0;
+  int rows = 2048, cols = 2048, steps = 50, warmup = 5, edge_rows = 16, check = 0, emulate = 0, one_gpu = 0;
   std::string id_file;
 };
 
@@ -75,7 +80,7 @@ void make_slab(int R, int C, int row0, int Rg, const lbm_geom& g, const lbm_bc& 
 }
 
 int run_rank(const Args& a, int rank, int world, int local_rank) {
-  check(lbm_set_device(local_rank), "lbm_set_device");
+  check(lbm_set_device(a.one_gpu ? 0 : local_rank), "lbm_set_device");
   const int R = a.rows, C = a.cols, Rg = R * world, G = 3;
   const lbm_cg_params prm = rt_params();
   lbm_geom g{R, C, G, 0};
@@ -157,14 +162,141 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   }
   if (rank == 0) {
     std::printf("{\"driver\": \"slab_ring_rt\", \"n_gpus\": %d, \"rows_per_gpu\": %d, \"cols\": %d, \"steps\": %d, "
-                "\"ms_per_step\": %.4f, \"mlups\": %.1f, \"transport\": \"rccl send/recv (C++ ring)\"%s}\n",
+                "\"ms_per_step\": %.4f, \"mlups\": %.1f, \"transport\": \"%s (C++ ring)\"%s}\n",
                 world, R, C, a.steps, 1e3 * tmax / a.steps, (double)Rg * C * a.steps / tmax / 1e6,
+                lbm_ring_transport(ring) == LBM_RING_IPC ? "peer-mapped windows" : "rccl send/recv",
                 a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
     std::fflush(stdout);
   }
   lbm_ring_destroy(ring);
   for (int b = 0; b < 2; ++b)
     for (int k = 0; k < 2; ++k) lbm_free(lat[b][k]);
+  return bad ? 3 : 0;
+}
+
+// --emulate N: every slab of the chain in turn on ONE GPU; the messages of lbm_ring_cg_step (LBM_HALO_TWO_PHASE: 21 rows per
+// colour and side) travel by device copies.  Same kernels on the same row ranges as a rank of the ring runs.
+int run_emulated(const Args& a, int N) {
+  check(lbm_set_device(0), "lbm_set_device");
+  const int R = a.rows, C = a.cols, Rg = R * N, G = 3, E = a.edge_rows < G ? G : a.edge_rows;
+  if (2 * E >= R) throw std::runtime_error("--edge-rows too large for these slabs");
+  const lbm_cg_params prm = rt_params();
+  const lbm_geom g{R, C, G, 0};
+  const size_t plane = (size_t)(R + 2 * G) * C, msg = (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * C;
+  struct Slab {
+    lbm_bc bc;
+    double* lat[2][2];   // [buffer][colour]
+    double* buf[2][2];   // [side][send / recv], both colours back to back
+    double ms = 0;
+  };
+  std::vector<Slab> S(N);
+  for (int r = 0; r < N; ++r) {
+    lbm_cg_default_bc(&S[r].bc);
+    if (r > 0) S[r].bc.row_lo = LBM_EDGE_HALO;
+    if (r < N - 1) S[r].bc.row_hi = LBM_EDGE_HALO;
+    make_slab(R, C, r * R, Rg, g, S[r].bc, prm, &S[r].lat[0][0], &S[r].lat[0][1]);
+    for (int k = 0; k < 2; ++k) {
+      check(lbm_malloc((void**)&S[r].lat[1][k], 9 * plane * 8), "lbm_malloc");
+      check(lbm_memset(S[r].lat[1][k], 0, 9 * plane * 8, nullptr), "memset");
+    }
+    for (int side = 0; side < 2; ++side)
+      for (int k = 0; k < 2; ++k) check(lbm_malloc((void**)&S[r].buf[side][k], 2 * msg * 8), "lbm_malloc");
+  }
+  auto pack = [&](int r, int cur) {
+    for (int k = 0; k < 2; ++k) {
+      if (r > 0) check(lbm_halo_pack(S[r].buf[0][0] + k * msg, S[r].lat[cur][k], &g, LBM_HALO_TWO_PHASE, 0, nullptr), "lbm_halo_pack");
+      if (r < N - 1) check(lbm_halo_pack(S[r].buf[1][0] + k * msg, S[r].lat[cur][k], &g, LBM_HALO_TWO_PHASE, 1, nullptr), "lbm_halo_pack");
+    }
+  };
+  auto deliver = [&]() {
+    for (int r = 0; r + 1 < N; ++r) {
+      check(lbm_memcpy_d2d(S[r + 1].buf[0][1], S[r].buf[1][0], 2 * msg * 8, nullptr), "d2d");
+      check(lbm_memcpy_d2d(S[r].buf[1][1], S[r + 1].buf[0][0], 2 * msg * 8, nullptr), "d2d");
+    }
+  };
+  auto unpack = [&](int r, int cur) {
+    for (int k = 0; k < 2; ++k) {
+      if (r > 0) check(lbm_halo_unpack(S[r].lat[cur][k], S[r].buf[0][1] + k * msg, &g, LBM_HALO_TWO_PHASE, 0, nullptr), "lbm_halo_unpack");
+      if (r < N - 1) check(lbm_halo_unpack(S[r].lat[cur][k], S[r].buf[1][1] + k * msg, &g, LBM_HALO_TWO_PHASE, 1, nullptr), "lbm_halo_unpack");
+    }
+  };
+  int cur = 0;
+  for (int r = 0; r < N; ++r) pack(r, cur);
+  deliver();
+  for (int r = 0; r < N; ++r) unpack(r, cur);
+  std::vector<void*> ev(2 * N, nullptr);
+  for (auto& e : ev) check(lbm_event_create(&e), "lbm_event_create");
+  for (int i = 0; i < a.warmup + a.steps; ++i) {
+    for (int r = 0; r < N; ++r) {  // a slab's step: edge rows, interior rows, messages packed (what lbm_ring_cg_step enqueues)
+      check(lbm_event_record(ev[2 * r], nullptr), "event");
+      auto rows = [&](int r0, int r1) {
+        check(lbm_cg_step_fused(S[r].lat[cur ^ 1][0], S[r].lat[cur ^ 1][1], S[r].lat[cur][0], S[r].lat[cur][1], &g, &S[r].bc, &prm, r0, r1,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "lbm_cg_step_fused");
+      };
+      if (N > 1) {
+        rows(0, E);
+        rows(R - E, R);
+        rows(E, R - E);
+      } else {
+        rows(0, R);
+      }
+      pack(r, cur ^ 1);
+      check(lbm_event_record(ev[2 * r + 1], nullptr), "event");
+    }
+    deliver();
+    for (int r = 0; r < N; ++r) unpack(r, cur ^ 1);
+    for (int r = 0; r < N; ++r) {
+      float m = 0;
+      check(lbm_event_elapsed_ms(&m, ev[2 * r], ev[2 * r + 1]), "elapsed");
+      if (i >= a.warmup) S[r].ms += m;
+    }
+    cur ^= 1;
+  }
+  for (auto& e : ev) lbm_event_destroy(e);
+  int bad = 0;
+  if (a.check) {
+    lbm_geom gw{Rg, C, 0, 0};
+    lbm_bc bw;
+    lbm_cg_default_bc(&bw);
+    double *p[2], *q2[2];
+    make_slab(Rg, C, 0, Rg, gw, bw, prm, &p[0], &p[1]);
+    const size_t n = (size_t)9 * Rg * C;
+    for (int k = 0; k < 2; ++k) check(lbm_malloc((void**)&q2[k], n * 8), "lbm_malloc");
+    for (int t = 0; t < a.warmup + a.steps; ++t) {
+      check(lbm_cg_step_fused(q2[0], q2[1], p[0], p[1], &gw, &bw, &prm, 0, Rg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "lbm_cg_step_fused");
+      std::swap(p[0], q2[0]);
+      std::swap(p[1], q2[1]);
+    }
+    std::vector<double> want((size_t)R * C), got((size_t)R * C);
+    for (int k = 0; k < 2; ++k)
+      for (int q = 0; q < 9; ++q)
+        for (int r = 0; r < N; ++r) {
+          check(lbm_memcpy_d2h(want.data(), p[k] + (size_t)q * Rg * C + (size_t)r * R * C, want.size() * 8, nullptr), "d2h");
+          check(lbm_memcpy_d2h(got.data(), S[r].lat[cur][k] + q * plane + (size_t)G * C, got.size() * 8, nullptr), "d2h");
+          check(lbm_stream_sync(nullptr), "sync");
+          if (std::memcmp(want.data(), got.data(), want.size() * 8) != 0) ++bad;
+        }
+    for (int k = 0; k < 2; ++k) {
+      lbm_free(p[k]);
+      lbm_free(q2[k]);
+    }
+  }
+  double slowest = 0;
+  for (int r = 0; r < N; ++r) slowest = std::max(slowest, S[r].ms / a.steps);
+  std::printf("{\"driver\": \"slab_ring_rt\", \"mode\": \"emulated chain on one GPU\", \"slabs\": %d, \"rows_per_slab\": %d, \"cols\": %d, "
+              "\"global_rows\": %d, \"steps\": %d, \"edge_rows\": %d, \"message_rows_per_colour_and_side\": %d, \"slowest_slab_ms_per_step\": %.4f, "
+              "\"chain_mlups_at_the_slowest_slabs_pace\": %.1f, \"per_slab\": [",
+              N, R, C, Rg, a.steps, E, lbm_halo_rows(LBM_HALO_TWO_PHASE), slowest, (double)Rg * C / slowest / 1e3);
+  for (int r = 0; r < N; ++r)
+    std::printf("%s{\"slab\": %d, \"ms_per_step\": %.4f, \"mlups\": %.1f}", r ? ", " : "", r, S[r].ms / a.steps, (double)R * C / (S[r].ms / a.steps) / 1e3);
+  std::printf("]%s}\n", a.check ? (bad ? ", \"check\": \"MISMATCH\"" : ", \"check\": \"bitwise equal to one block\"") : "");
+  std::fflush(stdout);
+  for (auto& sb : S)
+    for (int x = 0; x < 2; ++x)
+      for (int k = 0; k < 2; ++k) {
+        lbm_free(sb.lat[x][k]);
+        lbm_free(sb.buf[x][k]);
+      }
   return bad ? 3 : 0;
 }
 
@@ -178,9 +310,14 @@ int main(int argc, char** argv) {
   a.warmup = std::atoi(arg_value(argc, argv, "--warmup", "5").c_str());
   a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "16").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
+  a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
+  a.one_gpu = std::atoi(arg_value(argc, argv, "--one-gpu", "0").c_str());
+  const std::string transport = arg_value(argc, argv, "--transport", "");
+  if (!transport.empty()) setenv("LBM_RING_TRANSPORT", transport.c_str(), 1);  // lbm_ring_unique_id / lbm_ring_create follow it
   a.id_file = arg_value(argc, argv, "--id-file", "/tmp/lbm_ring_id." + std::to_string((long)getpid()));
   const int spawn = std::atoi(arg_value(argc, argv, "--spawn", "0").c_str());
   try {
+    if (a.emulate > 0) return run_emulated(a, a.emulate);
     if (spawn > 0) {
       cleanup_ring_files(a.id_file, spawn);  // a stale id file of a killed run must not be picked up
       const int rc = spawn_ranks(spawn, [&](int r) { return run_rank(a, r, spawn, r); });

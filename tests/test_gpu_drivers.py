@@ -168,6 +168,38 @@ def test_slab_ring_rt_driver(tmp_path):
     assert line["check"] == "bitwise equal to one block"
 
 
+def test_slab_ring_rt_emulated_chain_of_four_slabs(tmp_path):
+    """BASELINE config 4's decomposition in small (mrtcg_rayleigh_taylor.cpp:413-478 with its walls :495-533 on the
+    outer slabs): 4 slabs in turn on one GPU, the two-colour 21-row messages by device copies, edge rows before
+    interior rows; == the single block bit for bit"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_rt")
+    r = subprocess.run([exe, "--emulate", "4", "--rows", "64", "--cols", "96", "--steps", "9", "--warmup", "2", "--edge-rows", "8",
+                        "--check", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block" and line["slabs"] == 4 and line["message_rows_per_colour_and_side"] == 21
+
+
+@pytest.mark.parametrize("driver,args", [
+    ("slab_ring_box", ["--rows", "96", "--cols", "160", "--steps", "3", "--warmup", "1", "--depth", "5", "--period", "2", "--edge-rows", "16"]),
+    ("slab_ring_box", ["--rows", "96", "--cols", "128", "--steps", "3", "--warmup", "1", "--depth", "3", "--model", "kbc", "--edge-rows", "16"]),
+    ("slab_ring_rt", ["--rows", "64", "--cols", "96", "--steps", "6", "--warmup", "2", "--edge-rows", "8"]),
+    ("slab_ring_cylinder", ["--rows", "128", "--cols", "160", "--diameter", "30", "--steps", "10", "--warmup", "5", "--edge-rows", "8"]),
+])
+def test_ring_drivers_with_three_real_ranks_on_one_gpu(tmp_path, driver, args):
+    """the C++ hosts of the multi-GPU path as they run on a node -- `--spawn 3`: three forked rank processes --, here all on
+    GPU 0 through the peer-mapped transport (--transport ipc --one-gpu 1); --check 1: rank 0 recomputes the domain as one
+    block and compares every rank's rows bit for bit"""
+    import json
+    exe = os.path.join(BIN, driver)
+    r = subprocess.run([exe, "--spawn", "3", "--transport", "ipc", "--one-gpu", "1", "--check", "1", "--id-file", str(tmp_path / "id")] + args,
+                       capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block" and line["n_gpus"] == 3
+
+
 def test_slab_ring_cylinder_driver(tmp_path):
     """C++ host of config 5 over slabs (drivers/slab_ring_cylinder.cpp on lbm_ring_ibm_start /
     lbm_ring_bgk_block_ibm): 5-step blocks, the band around the ROI in a compact replica beside the far
