@@ -145,6 +145,18 @@ int lbm_halo_pack(double* buf, const double* lattice, const lbm_geom* g, int dep
 int lbm_halo_unpack(double* lattice, const double* buf, const lbm_geom* g, int depth, int side,
                     lbm_stream_t s);
 
+/* ---- which implementation of a collision runs (field `form` of the parameter structs below) ----------
+ * Every model exists twice: in the reference's OPERATION ORDER (-ffp-contract=off, same expression order:
+ * bitwise equal to the CPU oracle) and REASSOCIATED (same mathematics, fewer operations, reciprocals, FMA
+ * decided per source expression: agreement to rounding, tolerances in tests/).  The choice is part of the
+ * parameters of a solver / a call, so two solvers in one process may differ; LBM_FORM_DEFAULT (0, what a
+ * zero-initialised struct holds) = the process-wide default of lbm_set_tuning ("bgk_fast", "kbc_fast",
+ * "cg_fused": reassociated unless set to 0).  Lattices with pressure rows, a body force or the
+ * incompressible equilibrium always run the reference order. */
+#define LBM_FORM_DEFAULT 0
+#define LBM_FORM_REFERENCE_ORDER 1
+#define LBM_FORM_REASSOCIATED 2
+
 /* ---- BGK (solver.cpp:23-74 fused with :76-131) ---------------------------------------- */
 typedef struct lbm_bgk_params {
   double omega;
@@ -159,6 +171,8 @@ typedef struct lbm_bgk_params {
      implies delta_form.  force_mode = 0: off. */
   int force_mode;
   double force_r, force_c, guo_a, guo_b;
+  int form; /* LBM_FORM_*: REASSOCIATED on a delta_form lattice = the reassociated model standing in for the delta
+               form (<= 1e-10 relative, not bitwise; the process-wide default needs "bgk_fast_delta" = 1 for that) */
 } lbm_bgk_params;
 
 /* P = collide(f): moments, equilibrium, collision of every node in place of one driver
@@ -202,6 +216,7 @@ int lbm_stream(double* f, const double* p, const lbm_geom* g, const lbm_bc* bc, 
 /* ---- KBC entropic central-moment collision (src/ulbm.cpp; BASELINE config 3) -------------- */
 typedef struct lbm_kbc_params {
   double s2; /* ulbm::d2q9::kbc ctor argument (src/ulbm.hpp:23) */
+  int form;  /* LBM_FORM_*; multi-step launches exist for the reassociated collision only */
 } lbm_kbc_params;
 /* kbc::eval_equilibrium (ulbm.cpp:248-263) on SoA m0[R][C], m1[2][R][C].  zero_u2 != 0 is the
  * state in which the driver calls it (ux2 = uy2 = 0 from the ctor, ulbm_double_shear_flow.cpp:96) */
@@ -254,6 +269,8 @@ typedef struct lbm_cg_params {
                        0: Fg only shifts the velocity, u += Fg/(2 rho) -- the static-droplet driver
                        comments the source out (mrtcg_static_droplet.cpp:513-514) */
   double delta;     /* interface half-width of the s_nu blend; the drivers hard-code 0.1 (:375) */
+  int form;         /* LBM_FORM_* for lbm_cg_solver_step: REFERENCE_ORDER = the two-pass kernels (lbm_cg_stream_moments +
+                       lbm_cg_stream_collide), REASSOCIATED = the one-launch step (lbm_cg_step_fused) */
 } lbm_cg_params;
 /* differential::x (dir 0, d/d row) and ::y (dir 1, d/d column): isotropic 5x5 finite
  * differences with replicate padding (src/differential.hpp:9-40, src/differential.cpp:3-33);
@@ -641,6 +658,10 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * outermost strips / rows next to a wall row through the wall-carrying one, on a helper stream; 0: one
  * wall-carrying launch; same bits).  value < 0 restores the default.  Measurements: DESIGN.md "BGK kernel variants". */
 int lbm_set_tuning(const char* key, int value);
+/* 1 when the library was built with EXPERIMENTS=1: the launch forms that were measured and not kept (tuning keys "sw_pair",
+ * "sw_pf2", "ibm_chain_kernel", "ring_edges_main", "cg_strip", "cg_strip2" = 1 / 2 / 4, "cg_merge") exist; 0: those keys are
+ * ignored */
+int lbm_build_has_experiments(void);
 /* an empty one-thread kernel ("k_lbm_marker") to cut a profiler trace at: measurement harnesses bracket the launches
  * whose counters they sum with two of these */
 int lbm_marker(int tag, lbm_stream_t s);

@@ -65,14 +65,17 @@ static bool use_fast_bgk(const lbm_bgk_params* prm, const lbm_bc* bc) {
   // delta form f - omega (f - feq) is the same polynomial as (1 - omega) f + omega feq: the reassociated model
   // may stand in for it, but only on request ("bgk_fast_delta" = 1) -- the cylinder and loop presets are held
   // bitwise to the oracle by default
-  return !prm->force_mode && !prm->incompressible && (!prm->delta_form || tuning("bgk_fast_delta", 0)) &&
-         !(bc && bc->pressure_rows) && tuning("bgk_fast", 1);
+  // prm->form decides; LBM_FORM_DEFAULT = the process-wide knobs
+  const bool wanted = prm->form == LBM_FORM_DEFAULT ? (tuning("bgk_fast", 1) && (!prm->delta_form || tuning("bgk_fast_delta", 0)))
+                                                    : prm->form == LBM_FORM_REASSOCIATED;
+  return wanted && !prm->force_mode && !prm->incompressible && !(bc && bc->pressure_rows);
 }
 
 static int check_bgk(const char* fn, const lbm_bgk_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->omega > 0.0 && prm->omega < 2.0, "%s: omega=%g outside (0, 2)", fn, prm->omega);
   LBM_REQUIRE(prm->force_mode == 0 || prm->force_mode == 1, "%s: force_mode=%d", fn, prm->force_mode);
+  LBM_REQUIRE(prm->form >= LBM_FORM_DEFAULT && prm->form <= LBM_FORM_REASSOCIATED, "%s: form=%d (LBM_FORM_*)", fn, prm->form);
   return LBM_OK;
 }
 

@@ -49,6 +49,7 @@ static int check_cg(const char* fn, const lbm_geom* g, const lbm_bc* bc, const l
   LBM_REQUIRE(g->ghost == 0 || g->ghost == 3, "%s: ghost=%d (the two-phase step needs 0 or 3 ghost rows)", fn, g->ghost);
   LBM_REQUIRE(p->red.rho_0 > 0 && p->blue.rho_0 > 0 && p->delta > 0, "%s: bad colour parameters", fn);
   LBM_REQUIRE(p->red.alpha < 1.0 && p->blue.alpha < 1.0, "%s: alpha must be < 1", fn);
+  LBM_REQUIRE(p->form >= LBM_FORM_DEFAULT && p->form <= LBM_FORM_REASSOCIATED, "%s: form=%d (LBM_FORM_*)", fn, p->form);
   return LBM_OK;
 }
 
@@ -107,12 +108,14 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     return LBM_OK;
   }
   const int inner = (rc.ir1 - rc.ir0) * (rc.ic1 - rc.ic0), frame = tiles - inner;
+#ifdef LBM_EXPERIMENTS
   if (frame > 0 && !tuning("cg_strip2", 0) && tuning("cg_merge", 0)) {  // frame + inner tiles in one dispatch (opt-in: measured level with the two-launch form, 15.24 k either way)
     if (psi) LBM_KLAUNCH((k_cg_fused_merged<TR, TC, WAVES, true>), dim3(frame + inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc, frame);
     else LBM_KLAUNCH((k_cg_fused_merged<TR, TC, WAVES, false>), dim3(frame + inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc, frame);
     LBM_CHECK_LAUNCH();
     return LBM_OK;
   }
+#endif
   // the frame (3-4 % of the tiles, latency-bound: 63 us on its own) goes FIRST and on the helper stream, so
   // that it runs beside the inner launch instead of behind it (fork / join through two events, launch.hpp)
   SwSideStream* sd = frame > 0 && tuning("cg_frame_beside", 1) ? sw_side_stream() : nullptr;
@@ -145,16 +148,25 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     if (sw4 == 21) { LBM_CG_S4(4) } else { LBM_CG_S4(8) }
 #undef LBM_CG_S4
   } else
+#ifdef LBM_EXPERIMENTS
   if (const int sw = (sw4 == 21 || sw4 == 22) ? 0 : sw4) {  // the inner rectangle through a register-ring strip kernel
+#else
+  if (const int sw = (sw4 == 11 || sw4 == 12) ? sw4 : 0) {  // 11 / 12: k_cg_strip3 (private 64-column windows, colour sums in LDS)
+#endif
     // 1, 2, 4: k_cg_strip2 (one wave per SIMD) with that many waves per workgroup; 11, 12: k_cg_strip3 (colour sums
     // of the ring rows in LDS, two waves per SIMD) with 1 / 2 waves per workgroup
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
     const int strips = (cb - ca + CG_SW2 - 1) / CG_SW2;
+#ifdef LBM_EXPERIMENTS
     const void* kfn = sw == 2 ? (psi ? (const void*)k_cg_strip2<2, true> : (const void*)k_cg_strip2<2, false>)
                     : sw == 1 ? (psi ? (const void*)k_cg_strip2<1, true> : (const void*)k_cg_strip2<1, false>)
                     : sw == 11 ? (psi ? (const void*)k_cg_strip3<1, true> : (const void*)k_cg_strip3<1, false>)
                     : sw == 12 ? (psi ? (const void*)k_cg_strip3<2, true> : (const void*)k_cg_strip3<2, false>)
                                : (psi ? (const void*)k_cg_strip2<4, true> : (const void*)k_cg_strip2<4, false>);
+#else
+    const void* kfn = sw == 11 ? (psi ? (const void*)k_cg_strip3<1, true> : (const void*)k_cg_strip3<1, false>)
+                               : (psi ? (const void*)k_cg_strip3<2, true> : (const void*)k_cg_strip3<2, false>);
+#endif
     const int wv = sw == 2 || sw == 12 ? 2 : (sw == 1 || sw == 11 ? 1 : 4);
     // rows per wave: at 16.8 M nodes the launch is only 1-3 rounds of resident waves deep -- a chunk height
     // that leaves the last round nearly empty costs up to a whole round; fit it to the resident wave slots
@@ -165,9 +177,11 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     }
     if (rpc > rb - ra) rpc = rb - ra;
     const int chunks = (rb - ra + rpc - 1) / rpc, n_waves = strips * chunks;
+#ifdef LBM_EXPERIMENTS
 #define LBM_CG_S2(KERNEL, WV)                                                                                      \
     if (psi) LBM_KLAUNCH((KERNEL<WV, true>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves); \
     else LBM_KLAUNCH((KERNEL<WV, false>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves);
+#endif
     const int xo = tuning("cg_strip_xcd", 0);  // strip3: XCD k takes the k-th contiguous eighth of the strip sequence (measured: no effect)
 #define LBM_CG_S3(WV)                                                                                              \
     {                                                                                                              \
@@ -175,10 +189,14 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
       if (psi) LBM_KLAUNCH((k_cg_strip3<WV, true>), dim3(grid3), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves, xo); \
       else LBM_KLAUNCH((k_cg_strip3<WV, false>), dim3(grid3), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves, xo); \
     }
+#ifdef LBM_EXPERIMENTS
     if (sw == 2) { LBM_CG_S2(k_cg_strip2, 2) } else if (sw == 1) { LBM_CG_S2(k_cg_strip2, 1) }
     else if (sw == 11) LBM_CG_S3(1) else if (sw == 12) LBM_CG_S3(2)
     else { LBM_CG_S2(k_cg_strip2, 4) }
 #undef LBM_CG_S2
+#else
+    if (sw == 11) LBM_CG_S3(1) else LBM_CG_S3(2)
+#endif
 #undef LBM_CG_S3
   } else
   if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
@@ -191,6 +209,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   return LBM_OK;
 }
 
+#ifdef LBM_EXPERIMENTS
 template <int WAVES>
 static int launch_cg_strip_t(double* pn_r, double* pn_b, const double* in_r, const double* in_b,
                              const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
@@ -207,6 +226,8 @@ static int launch_cg_strip_t(double* pn_r, double* pn_b, const double* in_r, con
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
+
+#endif  // LBM_EXPERIMENTS
 
 }  // namespace lbm
 
@@ -298,12 +319,14 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
   const CgFast cf = make_cg_fast(make_cg_consts(*prm));
   const MacroIdx mi = make_macro_idx(gg);
   hipStream_t st = as_stream(s);
+#ifdef LBM_EXPERIMENTS
   switch (tuning("cg_strip", 0)) {  // column-strip sliding window (opt-in: slower as written, cg_fused.hpp), waves per workgroup
     case 0: break;
     case 2: return launch_cg_strip_t<2>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 4: return launch_cg_strip_t<4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     default: return launch_cg_strip_t<1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
   }
+#endif
   switch (tuning("cg_tile", 4)) {  // default: 16x32 tiles budgeted for 4 waves per SIMD (128 VGPRs)
     case 0: return launch_cg_fused_t<8, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 2: return launch_cg_fused_t<8, 64, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
@@ -409,7 +432,7 @@ int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps) {
     if (!sv->post) {  // iteration on the given (rho, u): the driver's first pass through :431-464
       rc = lbm_cg_collide(dst[0], dst[1], src[0], src[1], sv->rho_r, sv->rho_b, sv->u, &sv->g,
                           &sv->bc, &sv->prm, sv->psi, sv->snu, sv->st);
-    } else if (tuning("cg_fused", 1)) {
+    } else if (sv->prm.form == LBM_FORM_DEFAULT ? tuning("cg_fused", 1) != 0 : sv->prm.form == LBM_FORM_REASSOCIATED) {
       // one launch per step; the observable fields are written by the last step of the call
       const bool last = (i == n_steps - 1);
       rc = lbm_cg_step_fused(dst[0], dst[1], src[0], src[1], &sv->g, &sv->bc, &sv->prm, 0, sv->g.R,

@@ -424,6 +424,14 @@ int lbm_set_tuning(const char* key, int value) {
 }
 int lbm_get_tuning(const char* key) { return key ? tuning(key, 0) : 0; }
 
+int lbm_build_has_experiments(void) {
+#ifdef LBM_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 // an empty one-thread kernel whose name a profiler trace can be cut at (bench.py brackets the launches whose PMC
 // counters it sums with two of these)
 __global__ void k_lbm_marker(int) {}

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(1024) void k_ibm_step(IbmDev d, int m_max, const do
   ibm_force_wg<OPT, MAXOWN>(d, m_max, u, rho, F_sum, p, g, omega, a, b, with_source, lds);
 }
 
+#ifdef LBM_EXPERIMENTS  // measured level with the launch chain and not kept (DESIGN.md "experiments"): make EXPERIMENTS=1
 // ---- the whole chain of a forced box in ONE launch ---------------------------------------------------------------
 // D x (single BGK step on the box lattice, forcing, source term) for a block of an immersed-boundary lattice, as one
 // kernel of a few workgroups that hold their compute units for the whole block: beside a grid-filling window launch
@@ -423,6 +424,7 @@ __global__ __launch_bounds__(1024) void k_ibm_box_chain(IbmDev d, int m_max, dou
     out = t_;
   }
 }
+#endif  // LBM_EXPERIMENTS
 
 // F_s = F.reshape(-1, 2).sum(0): one block, fixed-order tree -> reproducible
 __global__ __launch_bounds__(256) void k_ibm_sum(int n, const double* __restrict__ F_sum,
@@ -775,6 +777,10 @@ int ibm_step_window(lbm_ibm* ib, int row_off, int col_off, double* p, const lbm_
 int ibm_box_chain(lbm_ibm* ib, int row_off, int col_off, double* const box[2], int* cur, const lbm_geom* g,
                   const lbm_bgk_params* prm, bool fast_model, int D, double* xrho, double* xu, double a, double b,
                   hipStream_t st) {
+#ifndef LBM_EXPERIMENTS
+  (void)ib; (void)row_off; (void)col_off; (void)box; (void)cur; (void)g; (void)prm; (void)fast_model; (void)D; (void)xrho; (void)xu; (void)a; (void)b; (void)st;
+  return 1;  // the one-launch chain is an experiment (make EXPERIMENTS=1): callers run the launch chain
+#else
   LBM_REQUIRE(ib && box && cur && g && prm, "ibm_box_chain: NULL argument");
   const size_t lds = ((size_t)3 * ib->d.n_touched + 2 * (size_t)ib->d.n_markers) * sizeof(double);
   const int nwg = tuning("ibm_chain_wgs", 16);
@@ -817,6 +823,7 @@ int ibm_box_chain(lbm_ibm* ib, int row_off, int col_off, double* const box[2], i
   if (rc) return rc;
   if (D % 2) *cur ^= 1;
   return LBM_OK;
+#endif  // LBM_EXPERIMENTS
 }
 // 0: no launch of k_ibm_box_chain ever gave up at its grid barrier (synchronises the device word read)
 int ibm_chain_status(lbm_ibm* ib, hipStream_t st) {

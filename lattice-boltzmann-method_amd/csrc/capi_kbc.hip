@@ -204,7 +204,13 @@ namespace lbm {
 static int check_kbc(const char* fn, const lbm_kbc_params* prm) {
   LBM_REQUIRE(prm, "%s: NULL params", fn);
   LBM_REQUIRE(prm->s2 > 0.0 && prm->s2 <= 2.0, "%s: s2=%g outside (0, 2]", fn, prm->s2);
+  LBM_REQUIRE(prm->form >= LBM_FORM_DEFAULT && prm->form <= LBM_FORM_REASSOCIATED, "%s: form=%d (LBM_FORM_*)", fn, prm->form);
   return LBM_OK;
+}
+
+// the reassociated collision unless the parameters (or, for LBM_FORM_DEFAULT, the process-wide knob) ask for the reference order
+bool kbc_uses_fast_model(const lbm_kbc_params* prm) {
+  return prm->form == LBM_FORM_DEFAULT ? tuning("kbc_fast", 1) != 0 : prm->form == LBM_FORM_REASSOCIATED;
 }
 
 }  // namespace lbm
@@ -241,7 +247,7 @@ int lbm_kbc_collide(double* p, const double* f, const lbm_geom* g, const lbm_bc*
   int rc = check_kbc("lbm_kbc_collide", prm);
   if (rc) return rc;
   LBM_REQUIRE(!(bc && bc->pressure_rows), "lbm_kbc_collide: pressure rows need the moments of the source rows: use lbm_kbc_collide_first");
-  if (tuning("kbc_fast", 1))
+  if (kbc_uses_fast_model(prm))
     return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcFastModel(prm->s2), rho, u, as_stream(s));
   return launch_collide_only("lbm_kbc_collide", p, f, g, bc, KbcModel{prm->s2}, rho, u, as_stream(s));
 }
@@ -272,7 +278,7 @@ int lbm_kbc_stream_collide(double* p_new, const double* p_old, const lbm_geom* g
   // the reassociated collision (kbc.hpp) unless the caller asks for the reference operation order
   // (tuning "kbc_fast" = 0) or the pressure rows -- which re-collide their source rows in that order
   // -- are in use
-  if (tuning("kbc_fast", 1) && !(bc && bc->pressure_rows))
+  if (kbc_uses_fast_model(prm) && !(bc && bc->pressure_rows))
     return launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcFastModel(prm->s2),
                                  row_begin, row_end, rho, u, as_stream(s));
   rc = launch_stream_collide("lbm_kbc_stream_collide", p_new, p_old, g, bc, KbcModel{prm->s2},
@@ -294,7 +300,7 @@ int lbm_kbc_stream_collide_xn(double* p_new, const double* p_old, const lbm_geom
                               int row_begin, int row_end, lbm_stream_t s) {
   int rc = check_kbc("lbm_kbc_stream_collide_xn", prm);
   if (rc) return rc;
-  LBM_REQUIRE(tuning("kbc_fast", 1), "lbm_kbc_stream_collide_xn: multi-step launches exist for the reassociated collision only (kbc_fast = 1)");
+  LBM_REQUIRE(kbc_uses_fast_model(prm), "lbm_kbc_stream_collide_xn: multi-step launches exist for the reassociated collision only (form = LBM_FORM_REASSOCIATED, or the default with kbc_fast = 1)");
   LBM_REQUIRE(n_steps >= 2 && n_steps <= 4, "lbm_kbc_stream_collide_xn: %d steps per launch (supported: 2..4)", n_steps);
   return launch_stream_collide_sw_kbc("lbm_kbc_stream_collide_xn", p_new, p_old, g, bc,
                                       KbcFastModel(prm->s2), n_steps, row_begin, row_end, as_stream(s));

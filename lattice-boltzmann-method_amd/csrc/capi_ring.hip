@@ -361,6 +361,7 @@ int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* s
 template <class Rows, class Edges>
 static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main, Rows&& rows, Edges&& edges, bool full = false) {
   const int R = rg->g.R;
+#ifdef LBM_EXPERIMENTS
   if (tuning("ring_edges_main", 0)) {
     // Variant (opt-in): edge rows on the caller's stream in front of the interior, only the exchange on the ring's
     // stream.  Measured at N = 1 with self send / recv (profiles/r02_ring_dissect.txt): what a launch-step loses against
@@ -385,6 +386,7 @@ static int ring_step(lbm_ring* rg, double* dst, int edge_rows, hipStream_t main,
     LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
     return LBM_OK;
   }
+#endif  // LBM_EXPERIMENTS
   // edge stream starts after everything previously enqueued on main (src complete)
   LBM_CHECK_HIP(hipEventRecord(rg->main_done, main));
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));

@@ -393,7 +393,7 @@ static bool solver_can_fuse_steps(const lbm_solver* sv) {
   // periodic edges, or the wall types the sliding window carries (bounce-back, specular, velocity)
   const bool bgk = sv->model == LBM_MODEL_BGK;
   auto plain = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
-  const bool model_ok = bgk || (sv->model == LBM_MODEL_KBC && tuning("kbc_fast", 1));
+  const bool model_ok = bgk || (sv->model == LBM_MODEL_KBC && kbc_uses_fast_model(&sv->kbc));
   return model_ok && !sv->ibm && !b.pressure_rows && !bc_mixed_axis(make_bc(&b)) && plain(b.row_lo) && plain(b.row_hi) &&
          plain(b.col_lo) && plain(b.col_hi) && sv->g.C >= 64;
 }

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
                                            row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x, (int)gridDim.x);
 }
 
+#ifdef LBM_EXPERIMENTS  // the launch forms below were measured and not kept (DESIGN.md "experiments"): make EXPERIMENTS=1
 // frame tiles and inner tiles in ONE dispatch: workgroups [0, n_frame) run the frame instantiation (general boundary
 // gather), the rest the inner one (plain offsets).  The two-launch form either runs the frame behind the inner launch
 // (63 us) or beside it on a helper stream, whose event fork / join costs as much as it hides (profiles/r02_ring_dissect.txt).
@@ -682,6 +683,11 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_cg_strip2(
   }
 }
 
+
+#endif  // LBM_EXPERIMENTS
+#ifndef LBM_EXPERIMENTS
+constexpr int CG_SW2 = 56;  // output columns per wave of the strip kernels with private windows
+#endif
 
 // ---- third generation: two waves per SIMD -----------------------------------------------------------------
 // k_cg_strip2 needs ~390 registers (one wave per SIMD: every dependent chain of the collision is exposed).

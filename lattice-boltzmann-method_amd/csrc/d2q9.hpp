@@ -736,6 +736,7 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   (void)c_load;
 }
 
+#ifdef LBM_EXPERIMENTS
 // The same iteration with the level-1 inputs prefetched TWO rows ahead (plain edges only): three raw-row
 // buffers rotate with the unroll index K -- buffer K holds this iteration's row (loaded two iterations ago),
 // buffer (K + 2) % 3, consumed by the previous iteration, takes row i + 2.  One wave per SIMD leaves the
@@ -787,6 +788,7 @@ __device__ __forceinline__ void sw_iteration_pf2(double (&ring)[D > 1 ? D - 1 : 
     }
   }
 }
+#endif  // LBM_EXPERIMENTS
 
 // Register budget (ring 54*(D-1) VGPRs + prefetch 18 + working set) -> waves per SIMD the kernel
 // is compiled for: D = 2: 4, D = 3: 3, D = 4, 5: 2, deeper: 1 (only enforced for 4-wave blocks).
@@ -844,6 +846,7 @@ __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const doub
     for (int b = 0; b < 3; ++b)
 #pragma unroll
       for (int q = 0; q < Q; ++q) ring[a][b][q] = 1.0;  // warm-up garbage, never stored
+#ifdef LBM_EXPERIMENTS
   if constexpr (PF2 && !HAS_BC) {
     double raw[3][Q];
 #pragma unroll
@@ -866,6 +869,9 @@ __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const doub
     }
     return;
   }
+#else
+  static_assert(!PF2, "the two-row prefetch is an experiment (make EXPERIMENTS=1)");
+#endif
   double cur[Q];
   {  // level-1 inputs of iteration 0
     int rr[3] = {rbase + 1, rbase, rbase - 1};
@@ -950,6 +956,7 @@ __global__ __launch_bounds__(128, 1) void k_stream_collide_sw_walls(double* __re
   }
 }
 
+#ifdef LBM_EXPERIMENTS  // measured and not kept (DESIGN.md "experiments"): compiled only with make EXPERIMENTS=1
 // ---- paired strips: the waves of a workgroup own ADJACENT 64-column windows and hand each other the edge
 // columns of every level through LDS, so only the outer 2 (D - 1) columns of the GROUP are redundant: 120 of
 // 128 lanes (2 waves) or 248 of 256 (4 waves) produce output instead of 56 of 64, and a group's rows are read
@@ -1124,6 +1131,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_stream_collide_swp(
     swp_iteration<Model, D, WAVES, 3, NT_STORE>(ring, cur, ex, pn, po, g, m, i + 3, n_iter, rbase, R0, R1, cols, lane_ok, c, w, lane, last_row_needed);
   }
 }
+
+#endif  // LBM_EXPERIMENTS
 
 // Edge pass: recompute the boundary nodes (rows 0 / R-1 where they carry a fix-up, columns
 // 0 / C-1 where they do) with the full boundary gather and overwrite what the interior

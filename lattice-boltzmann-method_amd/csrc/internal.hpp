@@ -33,6 +33,8 @@ int ibm_step_window(lbm_ibm* ib, int row_off, int col_off, double* p, const lbm_
 int ibm_box_chain(lbm_ibm* ib, int row_off, int col_off, double* const box[2], int* cur, const lbm_geom* g,
                   const lbm_bgk_params* prm, bool fast_model, int D, double* xrho, double* xu, double a, double b,
                   hipStream_t st);
+// capi_kbc.hip: the same question for KBC
+bool kbc_uses_fast_model(const lbm_kbc_params* prm);
 // capi_bgk.hip: the model lbm_bgk_stream_collide picks for these parameters (reassociated or reference order)
 bool bgk_uses_fast_model(const lbm_bgk_params* prm, const lbm_bc* bc);
 // capi_core.hip: a box of n_rows x n_cols nodes, all 9 populations, between two lattices (rows in owned-row

@@ -395,6 +395,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
     return LBM_OK;
   }
   bool launched = false;
+#ifdef LBM_EXPERIMENTS
   if constexpr (std::is_same<Model, BgkFastModel>::value || std::is_same<Model, BgkModelT<0, 0>>::value) {
     // paired strips (d2q9.hpp k_stream_collide_swp): the 2 / 4 waves of a workgroup hand each other their edge columns
     const int pw = tuning("sw_pair", 0);
@@ -422,6 +423,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
       launched = true;
     }
   }
+#endif  // LBM_EXPERIMENTS
   if (!launched) {
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \

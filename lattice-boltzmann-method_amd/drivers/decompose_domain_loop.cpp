@@ -140,8 +140,8 @@ int main(int argc, char** argv) {
     lbm::check(lbm_links_finalize(links));
     std::cout << "links=" << lbm_links_count(links) << std::endl;
 
-    lbm_bgk_params pA{omega, 0, 1, 0, 0.0, 0.0, 0.0, 0.0};  // A: adve + (-omega (adve - equi)) (:152-158)
-    lbm_bgk_params pX{omega, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};  // B, C, D: solver::collision (:161-163)
+    lbm_bgk_params pA{omega, 0, 1, 0, 0.0, 0.0, 0.0, 0.0, LBM_FORM_DEFAULT};  // A: adve + (-omega (adve - equi)) (:152-158)
+    lbm_bgk_params pX{omega, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, LBM_FORM_DEFAULT};  // B, C, D: solver::collision (:161-163)
     double* adve[4] = {b[A].adve, b[B].adve, b[C].adve, b[D].adve};
     const double* coll[4] = {b[A].coll, b[B].coll, b[C].coll, b[D].coll};
     std::cout << "main loop starts" << std::endl;

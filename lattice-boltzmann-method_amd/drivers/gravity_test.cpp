@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
     bc.rho_inlet = rho_inlet;
     bc.rho_outlet = rho_outlet;
     const lbm_bgk_params prm{omega, /*incompressible=*/1, /*delta_form=*/1, /*force_mode=*/1,
-                             -0.0003, 0.0, 1.0 / 3.0, 1.0 / 9.0};  // Fg :87, ics2/ics4 :81-82
+                             -0.0003, 0.0, 1.0 / 3.0, 1.0 / 9.0, LBM_FORM_DEFAULT};  // Fg :87, ics2/ics4 :81-82
     lbm::Solver sv = lbm::Solver::bgk(H, W, prm, bc);
     sv.set_f(f_adve);
     std::vector<double> uh((size_t)H * W * 2, 0.0);

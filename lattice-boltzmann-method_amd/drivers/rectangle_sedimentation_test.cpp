@@ -160,7 +160,7 @@ int main(int argc, char* argv[]) {
     lbm::check(lbm_links_finalize(z2));
     std::cout << "links: f " << lbm_links_count(lf) << ", g " << lbm_links_count(lg) << std::endl;
 
-    lbm_bgk_params prm{lp.omega, 0, 0, 0, 0.0, 0.0, 0.0, 0.0};
+    lbm_bgk_params prm{lp.omega, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, LBM_FORM_DEFAULT};
     double* fa[1] = {f_adve.data()};
     const double* fc[1] = {f_coll.data()};
     double* ga[1] = {g_adve.data()};

@@ -75,7 +75,7 @@ double* make_slab(const Args& a, int R, int row0, int Rg, const lbm_geom& g, con
   // the collide-only launch that opens the post-collision-resident loop (ghost rows: collide of
   // zeros stays in the ghost rows and is overwritten by the first exchange)
   if (a.kbc) {
-    lbm_kbc_params kp{prm.omega};
+    lbm_kbc_params kp{prm.omega, LBM_FORM_DEFAULT};
     check(lbm_kbc_collide(post, pre, &g, nullptr, &kp, nullptr, nullptr, nullptr), "lbm_kbc_collide");
   } else {
     check(lbm_bgk_collide(post, pre, &g, nullptr, &prm, nullptr, nullptr, nullptr), "lbm_bgk_collide");
@@ -93,7 +93,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   lbm_geom g{R, C, G, 0};
   lbm_bgk_params prm{};
   prm.omega = a.omega;
-  lbm_kbc_params kprm{a.omega};
+  lbm_kbc_params kprm{a.omega, LBM_FORM_DEFAULT};
 
   unsigned char id[128];
   if (rank == 0) {

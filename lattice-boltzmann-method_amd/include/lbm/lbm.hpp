@@ -107,7 +107,7 @@ class Solver {  // single-phase BGK / KBC block, wraps lbm_solver
  public:
   static Solver bgk(int R, int C, double omega, bool incompressible, const lbm_bc& bc = BoundarySet(),
                     bool delta_form = false) {
-    lbm_bgk_params p{omega, incompressible ? 1 : 0, delta_form ? 1 : 0, 0, 0.0, 0.0, 0.0, 0.0};
+    lbm_bgk_params p{omega, incompressible ? 1 : 0, delta_form ? 1 : 0, 0, 0.0, 0.0, 0.0, 0.0, LBM_FORM_DEFAULT};
     return Solver(LBM_MODEL_BGK, R, C, &p, bc);
   }
   // full parameter block (e.g. the body force of test/gravity_test.cpp: force_mode = 1)
@@ -115,7 +115,7 @@ class Solver {  // single-phase BGK / KBC block, wraps lbm_solver
     return Solver(LBM_MODEL_BGK, R, C, &p, bc);
   }
   static Solver kbc(int R, int C, double s2, const lbm_bc& bc = BoundarySet()) {
-    lbm_kbc_params p{s2};
+    lbm_kbc_params p{s2, LBM_FORM_DEFAULT};
     return Solver(LBM_MODEL_KBC, R, C, &p, bc);
   }
   Solver(Solver&& o) noexcept : h_(o.h_), R_(o.R_), C_(o.C_) { o.h_ = nullptr; }
@@ -230,7 +230,7 @@ class kbc {
   lbm::Field m1;  // [R,C,2]
   kbc(int R, int C, double s2) : coll_f(R, C, 9), adve_f(R, C, 9), m0(R, C, 1), m1(R, C, 2), s2{s2} {}
   void collide() {  // ulbm.cpp:91-126, with the moments the members hold
-    lbm_kbc_params p{s2};
+    lbm_kbc_params p{s2, LBM_FORM_DEFAULT};
     lbm::check(lbm_kbc_collide_given_moments(coll_f.data(), adve_f.data(), m0.data(), m1.data(), &p,
                                              adve_f.rows(), adve_f.cols(), nullptr));
     warm_ = true;
@@ -319,7 +319,7 @@ class CgSolver {
            double delta = 0.1, double gravity_c = 0.0, bool add_source = true)
       : R_(R), C_(C) {
     lbm_geom g{R, C, 0, 0};
-    lbm_cg_params p{red.abi(), blue.abi(), sigma, gravity_r, gravity_c, add_source ? 1 : 0, delta};
+    lbm_cg_params p{red.abi(), blue.abi(), sigma, gravity_r, gravity_c, add_source ? 1 : 0, delta, LBM_FORM_DEFAULT};
     check(lbm_cg_solver_create(&h_, &g, nullptr, &p, nullptr));
   }
   CgSolver(const CgSolver&) = delete;

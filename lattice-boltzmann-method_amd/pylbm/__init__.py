@@ -19,6 +19,8 @@ HEADER = os.path.join(REPO, "include", "lbm_hip.h")
 EDGE_PERIODIC, EDGE_HALO, EDGE_BOUNCE_BACK, EDGE_SPECULAR, EDGE_ABB_VELOCITY, EDGE_WRAP_NOSHIFT = range(6)
 HALO_TWO_PHASE = -3  # lbm_halo_pack / _unpack depth code of the colour-gradient step (21 rows)
 MODEL_BGK, MODEL_KBC = 0, 1
+FORM_DEFAULT, FORM_REFERENCE_ORDER, FORM_REASSOCIATED = 0, 1, 2   # field `form` of the parameter structs (LBM_FORM_*)
+RING_DEFAULT, RING_RCCL, RING_IPC = -1, 0, 1
 
 _dp = ct.POINTER(ct.c_double)
 
@@ -48,18 +50,21 @@ class Bc(ct.Structure):
 class BgkParams(ct.Structure):
     _fields_ = [("omega", ct.c_double), ("incompressible", ct.c_int), ("delta_form", ct.c_int),
                 ("force_mode", ct.c_int), ("force_r", ct.c_double), ("force_c", ct.c_double),
-                ("guo_a", ct.c_double), ("guo_b", ct.c_double)]
+                ("guo_a", ct.c_double), ("guo_b", ct.c_double), ("form", ct.c_int)]
 
-    def __init__(self, omega=1.0, incompressible=0, delta_form=0, force=None, guo=(1.0 / 3.0, 1.0 / 9.0)):
-        """force=(Fr, Fc): the body force of test/gravity_test.cpp (u += F, Guo-type source)"""
+    def __init__(self, omega=1.0, incompressible=0, delta_form=0, force=None, guo=(1.0 / 3.0, 1.0 / 9.0), form=FORM_DEFAULT):
+        """force=(Fr, Fc): the body force of test/gravity_test.cpp (u += F, Guo-type source); form: FORM_*"""
         if force is None:
-            super().__init__(omega, incompressible, delta_form, 0, 0.0, 0.0, 0.0, 0.0)
+            super().__init__(omega, incompressible, delta_form, 0, 0.0, 0.0, 0.0, 0.0, form)
         else:
-            super().__init__(omega, incompressible, 1, 1, force[0], force[1], guo[0], guo[1])
+            super().__init__(omega, incompressible, 1, 1, force[0], force[1], guo[0], guo[1], form)
 
 
 class KbcParams(ct.Structure):
-    _fields_ = [("s2", ct.c_double)]
+    _fields_ = [("s2", ct.c_double), ("form", ct.c_int)]
+
+    def __init__(self, s2=1.0, form=FORM_DEFAULT):
+        super().__init__(s2, form)
 
 
 class CgColour(ct.Structure):
@@ -70,7 +75,7 @@ class CgColour(ct.Structure):
 class CgParams(ct.Structure):
     _fields_ = [("red", CgColour), ("blue", CgColour), ("sigma", ct.c_double),
                 ("gravity_r", ct.c_double), ("gravity_c", ct.c_double), ("add_source", ct.c_int),
-                ("delta", ct.c_double)]
+                ("delta", ct.c_double), ("form", ct.c_int)]
 
 
 class LbmError(RuntimeError):
@@ -121,7 +126,7 @@ class Lib:
         return int(self.raw.lbm_default_plane_pad(R, C))
 
     def reset_tuning(self):
-        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd", b"kbc_fast", b"kbc_depth", b"bgk_fast", b"cg_strip", b"cg_rows", b"cg_split", b"sw_split", b"solver_depth_walls", b"ibm_depth", b"ibm_gate", b"bgk_fast_delta", b"pressure_depth", b"halo_grid", b"cg_strip2", b"cg_rows2", b"sw_pair", b"sw_pf2", b"cg_strip_xcd", b"cg_merge", b"cg_frame_beside", b"ring_period", b"ibm_step_opt", b"ibm_step_split", b"ibm_step_chain", b"ibm_box", b"ibm_box_overlap", b"bg_priority", b"ibm_chain_kernel", b"ibm_chain_wgs", b"ibm_box_sole"):
+        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd", b"kbc_fast", b"kbc_depth", b"bgk_fast", b"cg_strip", b"cg_rows", b"cg_split", b"sw_split", b"solver_depth_walls", b"ibm_depth", b"ibm_gate", b"bgk_fast_delta", b"pressure_depth", b"halo_grid", b"cg_strip2", b"cg_rows2", b"sw_pair", b"sw_pf2", b"cg_strip_xcd", b"cg_merge", b"cg_frame_beside", b"ring_period", b"ibm_step_opt", b"ibm_step_split", b"ibm_step_chain", b"ibm_box", b"ibm_box_overlap", b"bg_priority", b"ibm_chain_kernel", b"ibm_chain_wgs", b"ibm_box_sole", b"sw_ldsring", b"ring_ipc_timeout_ms"):
             self.set_tuning(k, -1)
 
 
@@ -215,10 +220,10 @@ class Solver:
 
 
 def cg_params(red=(3.0, 0.7, 0.04, 0.7), blue=(1.0, 0.1, 0.04, -0.7), sigma=0.1, gravity=6.25e-6,
-              delta=0.1, gravity_c=0.0, add_source=1):
+              delta=0.1, gravity_c=0.0, add_source=1, form=FORM_DEFAULT):
     """[red]/[blue] of mrtcg-rayleigh-taylor-gamma3.toml as (rho_0, alpha, nu, beta); sigma and
     gravity are this build's recorded choices for the keys the shipped TOML lacks."""
-    return CgParams(CgColour(*red), CgColour(*blue), sigma, gravity, gravity_c, add_source, delta)
+    return CgParams(CgColour(*red), CgColour(*blue), sigma, gravity, gravity_c, add_source, delta, form)
 
 
 class CgSolver:

@@ -913,6 +913,8 @@ def test_paired_strip_and_deep_prefetch_windows_bit_identical(lib, oracle, R, C)
     barrier per iteration) and "sw_pf2" = 1 (level-1 rows prefetched two iterations ahead).  Same arithmetic
     per node: 2 launches == 10 single steps == oracle bit for bit; partial last group, chunks that do not divide
     R, column counts that wrap inside a group."""
+    if not lib.raw.lbm_build_has_experiments():
+        pytest.skip("paired strips / two-row prefetch are experiments: make -C lattice-boltzmann-method_amd/csrc EXPERIMENTS=1")
     f0 = random_state(oracle, R, C, seed=7 * R + C)
     prm = pylbm.BgkParams(1.5, 0)
     g = pylbm.Geom(R, C, 0)

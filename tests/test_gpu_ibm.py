@@ -259,6 +259,8 @@ def test_forced_box_variants_equal_the_oracle(lib, oracle, tune, cy_frac):
     """The forced BOX of an immersed-boundary block (rows and columns ROI +- 2 D on a small lattice of its own,
     D-step window over all rows beside it) and every switch around it: same bits as the oracle after 16 steps
     (1 + three 5-step blocks), same surface force; the blocks really ran (lbm_solver_block_launches)."""
+    if tune.get("ibm_chain_kernel") and not lib.raw.lbm_build_has_experiments():
+        pytest.skip("the one-launch forcing chain is an experiment: make -C lattice-boltzmann-method_amd/csrc EXPERIMENTS=1")
     X, Y, omega, u_in, radius = 176, 200, 1.0 / 0.55, 0.05, 9.0
     x, y = circle(X * 0.45 + 0.3, Y * cy_frac - 0.4, radius)
     u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in

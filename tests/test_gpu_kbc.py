@@ -308,3 +308,46 @@ def test_kbc_sliding_window_carries_walls(lib, oracle):
             lib.kbc_stream_collide_xn(_ptr(b), _ptr(p0), ct.byref(g), ct.byref(bc), ct.byref(prm), D, 0, R, None)
             torch.cuda.synchronize()
             assert torch.equal(b, src), (rows_too, D, float((b - src).abs().max()))
+
+
+def test_two_solvers_with_different_collision_forms_coexist(lib, oracle):
+    """the collision form is a field of the parameter structs, not process-wide state -- a
+    reference-order solver and a reassociated one, BGK and KBC, stepped in turns inside one process.  Each equals the
+    same solver run alone bit for bit; the reference-order ones equal the oracle bit for bit; the process-wide knobs
+    stay at their defaults throughout."""
+    R, C, n = 96, 128, 12
+    rng = np.random.default_rng(5)
+    rho = 1 + 0.01 * rng.standard_normal((R, C))
+    u = 0.03 * rng.standard_normal((R, C, 2))
+    f0 = oracle.equilibrium(u, rho)
+    s2 = 1.0 / (0.5 + 3 * 1.7e-4)
+
+    def make(model, form):
+        prm = pylbm.BgkParams(1.3, 0, form=form) if model == pylbm.MODEL_BGK else pylbm.KbcParams(s2, form)
+        sv = pylbm.Solver(lib, model, R, C, prm)
+        sv.set_f(f0)
+        return sv
+
+    kinds = [(pylbm.MODEL_BGK, pylbm.FORM_REFERENCE_ORDER), (pylbm.MODEL_BGK, pylbm.FORM_REASSOCIATED),
+             (pylbm.MODEL_KBC, pylbm.FORM_REFERENCE_ORDER), (pylbm.MODEL_KBC, pylbm.FORM_REASSOCIATED)]
+    alone = []
+    for k in kinds:
+        sv = make(*k)
+        sv.step(n)
+        alone.append(sv.get_f())
+        sv.close()
+    svs = [make(*k) for k in kinds]
+    for chunk in (1, 5, 3, 3):                 # turns of different lengths: multi-step launches and remainders interleave
+        for sv in svs:
+            sv.step(chunk)
+    together = [sv.get_f() for sv in svs]
+    for sv in svs:
+        sv.close()
+    for k, a, t in zip(kinds, alone, together):
+        assert bits_equal(a, t), (k, ulp_diff(a, t))
+    assert not bits_equal(together[0], together[1]) and not bits_equal(together[2], together[3])   # the forms really differ
+    assert relerr(together[1], together[0]) < 1e-12 and relerr(together[3], together[2]) < 1e-11
+    f_o, _, _ = oracle.bgk_periodic_steps(f0, 1.3, n)
+    assert bits_equal(together[0], f_o), ulp_diff(together[0], f_o)
+    for key in (b"bgk_fast", b"kbc_fast"):
+        assert lib.raw.lbm_get_tuning(key) == 0      # unset (lbm_get_tuning reports 0 for keys nobody set)
