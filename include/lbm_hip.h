@@ -542,6 +542,18 @@ int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const do
 typedef struct lbm_slab_pressure lbm_slab_pressure;
 int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
                              const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth);
+/* the same for KBC (test/ulbm_poiseuille.cpp:36-58, :85-139: KBC + pressure rows + wall columns): blocks of 2 steps (the
+ * depth of the reference-order KBC window, as on one block); block_compute / block_finish / msg_doubles are shared.  The
+ * driver's first iteration collides on HELD moments (kbc.m0, kbc.m1, :85-86): the start-up calls take them for the slab's
+ * owned rows (m0 [R][C], m1 [2][R][C]); across the pressure seam the message carries the 2 D rows and their moments (12
+ * planes).  After start_finish_kbc the ghost rows of `post` are not current: exchange complete halos (LBM_HALO_FULL(2)) over
+ * the ordinary seams before the first block (lbm_ring_pressure_start_kbc does). */
+int lbm_slab_pressure_create_kbc(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
+                                 const lbm_bc* bc_global, const lbm_kbc_params* prm);
+int lbm_slab_pressure_start_pack_kbc(lbm_slab_pressure* sl, const double* pre, const double* m0, const double* m1,
+                                     double* send_prev, double* send_next, lbm_stream_t s);
+int lbm_slab_pressure_start_finish_kbc(lbm_slab_pressure* sl, double* post, double* pre, const double* m0, const double* m1,
+                                       const double* recv_prev, const double* recv_next, lbm_stream_t s);
 int lbm_slab_pressure_destroy(lbm_slab_pressure* sl);
 int lbm_slab_pressure_info(const lbm_slab_pressure* sl, int* R, int* C, int* ghost, int* depth); /* any output may be NULL */
 long long lbm_slab_pressure_msg_doubles(const lbm_slab_pressure* sl, int side, int start /* 1: the start-up exchange */);
@@ -554,7 +566,10 @@ int lbm_slab_pressure_block_compute(lbm_slab_pressure* sl, double* dst, const do
 int lbm_slab_pressure_block_finish(lbm_slab_pressure* sl, double* dst, const double* recv_prev, const double* recv_next, lbm_stream_t s);
 /* the same over the slab ring (created periodic): start-up, then one block per call (exchange behind the compute) */
 int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, lbm_stream_t main);
-int lbm_ring_bgk_block_pressure(lbm_ring* rg, lbm_slab_pressure* sl, double* dst, const double* src, lbm_stream_t main);
+int lbm_ring_bgk_block_pressure(lbm_ring* rg, lbm_slab_pressure* sl, double* dst, const double* src, lbm_stream_t main); /* BGK and KBC slabs alike */
+/* KBC start-up over the ring: held moments of the owned rows; ends with the complete-halo exchange of `post` */
+int lbm_ring_pressure_start_kbc(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, const double* m0,
+                                const double* m1, lbm_stream_t main);
 
 /* ---- population links between lattices on one GPU (multi-block topologies) -----------------------
  * The reference glues blocks by slice assignments after advect (test/decompose_domain.cpp:181-187;

@@ -182,10 +182,11 @@ int lbm::kbc_stream_collide_x2_ref(double* pn, const double* po, const lbm_geom*
   LBM_REQUIRE(pn && po && pn != po && prm, "%s: bad argument", fn);
   LBM_REQUIRE(0 <= row_begin && row_begin <= row_end && row_end <= lg->R, "%s: row range", fn);
   const Bc bc = make_bc(lbc);
-  auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || bc_is_wall(m); };
-  LBM_REQUIRE(lg->ghost == 0 && carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) &&
+  // (slabs: ghost >= 2 rows behind HALO edges -- the far rows of a slab of a lattice with pressure rows, capi_slab_pressure.hip)
+  auto carried = [](int m) { return m == LBM_EDGE_PERIODIC || m == LBM_EDGE_HALO || bc_is_wall(m); };
+  LBM_REQUIRE((lg->ghost == 0 || lg->ghost >= 2) && carried(bc.row_lo) && carried(bc.row_hi) && carried(bc.col_lo) && carried(bc.col_hi) &&
                   !bc.pressure_rows && !bc_mixed_axis(bc) && lg->R >= 16 && lg->C >= 64,
-              "%s: single block with periodic / wall edges only", fn);
+              "%s: periodic / halo / wall edges only (ghost rows: 0 or >= 2)", fn);
   if (row_begin == row_end) return LBM_OK;
   const Geom g = make_geom(*lg);
   const KbcModel m{prm->s2};

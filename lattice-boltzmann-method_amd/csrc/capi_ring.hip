@@ -707,7 +707,18 @@ int lbm_ring_bgk_block_ibm(lbm_ring* rg, lbm_slab_ibm* sl, double* dst, const do
 }
 
 // ---- pressure-periodic rows over the (periodic) ring: capi_slab_pressure.hip holds the engine ---------------------
+static int ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, const double* m0, const double* m1,
+                               lbm_stream_t main_s);
 int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, lbm_stream_t main_s) {
+  return ring_pressure_start(rg, sl, post, pre, nullptr, nullptr, main_s);
+}
+int lbm_ring_pressure_start_kbc(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, const double* m0,
+                                const double* m1, lbm_stream_t main_s) {
+  LBM_REQUIRE(m0 && m1, "lbm_ring_pressure_start_kbc: NULL moments");
+  return ring_pressure_start(rg, sl, post, pre, m0, m1, main_s);
+}
+static int ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, double* pre, const double* m0, const double* m1,
+                               lbm_stream_t main_s) {
   LBM_REQUIRE(rg && sl && post && pre, "lbm_ring_pressure_start: NULL argument");
   LBM_REQUIRE(rg->prev >= 0 && rg->next >= 0 && rg->nranks >= 2, "lbm_ring_pressure_start: needs a periodic ring of at least 2 slabs");
   {
@@ -730,9 +741,17 @@ int lbm_ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post, d
     rc = LBM_ERR_HIP;
   }
   hipStream_t main = as_stream(main_s);
-  if (!rc) rc = lbm_slab_pressure_start_pack(sl, pre, buf[0], buf[2], main_s);
+  if (!rc) rc = m0 ? lbm_slab_pressure_start_pack_kbc(sl, pre, m0, m1, buf[0], buf[2], main_s) : lbm_slab_pressure_start_pack(sl, pre, buf[0], buf[2], main_s);
   if (!rc) rc = ring_sendrecv(rg, buf[0], n_prev, buf[1], n_prev, buf[2], n_next, buf[3], n_next, main);
-  if (!rc) rc = lbm_slab_pressure_start_finish(sl, post, pre, buf[1], buf[3], main_s);
+  if (!rc) rc = m0 ? lbm_slab_pressure_start_finish_kbc(sl, post, pre, m0, m1, buf[1], buf[3], main_s)
+                   : lbm_slab_pressure_start_finish(sl, post, pre, buf[1], buf[3], main_s);
+  if (!rc && m0) {  // KBC: the collision on held moments left the ghost rows of `post` behind: complete halos over every seam
+    rc = ring_exchange(rg, post, nullptr, main, true);
+    if (!rc) {
+      LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
+      LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+    }
+  }
   if (!rc && hipStreamSynchronize(main) != hipSuccess) {
     set_error("lbm_ring_pressure_start: stream synchronisation failed");
     rc = LBM_ERR_HIP;

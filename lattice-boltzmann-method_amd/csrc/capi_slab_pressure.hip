@@ -19,6 +19,9 @@
 using namespace lbm;
 
 struct lbm_slab_pressure {
+  int model;               // LBM_MODEL_BGK / LBM_MODEL_KBC
+  lbm_kbc_params kprm;     // KBC: blocks of 2 steps, far rows through the reference-order 2-step window
+  double *sm0, *sm1;       // KBC: the held moments of the small lattice's rows for the driver's first iteration
   lbm_geom g;
   int row0, rows_global, D;
   lbm_bc bc_seam, bc_far;  // the small lattice's edges (= the domain's, pressure rows on); this slab's far rows (HALO rows, no pressure rows)
@@ -56,15 +59,33 @@ int lbm_slab_pressure_destroy(lbm_slab_pressure* sl) {
   }
   if (sl->ev_fork) (void)hipEventDestroy(sl->ev_fork);
   if (sl->ev_join) (void)hipEventDestroy(sl->ev_join);
-  for (double* p : {sl->slat[0], sl->slat[1], sl->stash})
+  for (double* p : {sl->slat[0], sl->slat[1], sl->stash, sl->sm0, sl->sm1})
     if (p) (void)hipFree(p);
   delete sl;
   return LBM_OK;
 }
 
+static int slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
+                                const lbm_bc* bc_global, const lbm_bgk_params* prm, const lbm_kbc_params* kprm, int depth);
+
 int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
                              const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth) {
-  LBM_REQUIRE(out && slab && bc_global && prm, "lbm_slab_pressure_create: NULL argument");
+  LBM_REQUIRE(prm, "lbm_slab_pressure_create: NULL argument");
+  return slab_pressure_create(out, slab, slab_row0, rows_global, bc_global, prm, nullptr, depth);
+}
+
+// KBC + pressure-periodic rows (test/ulbm_poiseuille.cpp:36-58, :85-139) over slabs: blocks of 2 steps (the depth of the
+// reference-order KBC window, as on one block); the driver's first iteration collides on HELD moments (:85-86), which the
+// start-up calls below take per slab
+int lbm_slab_pressure_create_kbc(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
+                                 const lbm_bc* bc_global, const lbm_kbc_params* prm) {
+  LBM_REQUIRE(prm && prm->s2 > 0.0 && prm->s2 <= 2.0, "lbm_slab_pressure_create_kbc: bad parameters");
+  return slab_pressure_create(out, slab, slab_row0, rows_global, bc_global, nullptr, prm, 2);
+}
+
+static int slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
+                                const lbm_bc* bc_global, const lbm_bgk_params* prm, const lbm_kbc_params* kprm, int depth) {
+  LBM_REQUIRE(out && slab && bc_global, "lbm_slab_pressure_create: NULL argument");
   const int R = slab->R, C = slab->C, D = depth;
   LBM_REQUIRE(D >= 2 && D <= 5, "lbm_slab_pressure_create: depth=%d (supported: 2..5)", D);
   LBM_REQUIRE(slab->ghost >= D && R >= 6 * D + 8 && C >= 64, "lbm_slab_pressure_create: slab %dx%d with %d ghost rows too small for %d-step blocks", R, C, slab->ghost, D);
@@ -81,7 +102,12 @@ int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int 
   sl->row0 = slab_row0;
   sl->rows_global = rows_global;
   sl->D = D;
-  sl->prm = *prm;
+  sl->model = kprm ? LBM_MODEL_KBC : LBM_MODEL_BGK;
+  if (prm) sl->prm = *prm;
+  if (kprm) {
+    sl->kprm = *kprm;
+    sl->kprm.form = LBM_FORM_REFERENCE_ORDER;  // lattices with pressure rows keep the reference order on every path
+  }
   sl->bc_seam = *bc_global;
   sl->bc_far = *bc_global;
   sl->bc_far.pressure_rows = 0;
@@ -101,6 +127,10 @@ int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int 
   }
   if (e == hipSuccess) e = hipMalloc(&sl->stash, stash_bytes);
   if (e == hipSuccess) e = hipMemset(sl->stash, 0, stash_bytes);
+  if (kprm) {
+    if (e == hipSuccess) e = hipMalloc(&sl->sm0, (size_t)4 * D * C * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&sl->sm1, (size_t)8 * D * C * sizeof(double));
+  }
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&sl->aux, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&sl->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&sl->ev_join, hipEventDisableTiming);
@@ -118,13 +148,16 @@ int lbm_slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int 
 long long lbm_slab_pressure_msg_doubles(const lbm_slab_pressure* sl, int side, int start) {
   if (!sl) return -1;
   const bool seam = (side == 0 && sl->first) || (side == 1 && sl->last);
-  return (long long)9 * (start && seam ? 2 * sl->D : sl->D) * sl->g.C;
+  // (KBC start-up across the pressure seam: the 2 D rows AND their held moments m0, m1: 9 + 3 planes)
+  const int planes = (start && seam && sl->model == LBM_MODEL_KBC) ? 12 : 9;
+  return (long long)planes * (start && seam ? 2 * sl->D : sl->D) * sl->g.C;
 }
 
 // start-up, on the driver's PRE-collision state: complete D-row halos across ordinary seams, the 2 D rows next to
 // the pressure seam across that one
 int lbm_slab_pressure_start_pack(lbm_slab_pressure* sl, const double* pre, double* send_prev, double* send_next, lbm_stream_t s) {
   LBM_REQUIRE(sl && pre && send_prev && send_next, "lbm_slab_pressure_start_pack: NULL argument");
+  LBM_REQUIRE(sl->model == LBM_MODEL_BGK, "lbm_slab_pressure_start_pack: a KBC slab starts with lbm_slab_pressure_start_pack_kbc (held moments)");
   const int R = sl->g.R, C = sl->g.C, D = sl->D, full = LBM_HALO_FULL(D);
   const lbm_geom mg = msg_geom(2 * D, C);
   int rc = sl->first ? lbm_rows_copy(send_prev, &mg, 0, pre, &sl->g, 0, 2 * D, s) : lbm_halo_pack(send_prev, pre, &sl->g, full, 0, s);
@@ -138,6 +171,7 @@ int lbm_slab_pressure_start_pack(lbm_slab_pressure* sl, const double* pre, doubl
 int lbm_slab_pressure_start_finish(lbm_slab_pressure* sl, double* post, double* pre, const double* recv_prev,
                                    const double* recv_next, lbm_stream_t s) {
   LBM_REQUIRE(sl && post && pre && post != pre && recv_prev && recv_next, "lbm_slab_pressure_start_finish: bad argument");
+  LBM_REQUIRE(sl->model == LBM_MODEL_BGK, "lbm_slab_pressure_start_finish: a KBC slab starts with lbm_slab_pressure_start_finish_kbc");
   const int R = sl->g.R, C = sl->g.C, D = sl->D, G = sl->g.ghost, full = LBM_HALO_FULL(D);
   hipStream_t st = as_stream(s);
   int rc = LBM_OK;
@@ -172,6 +206,96 @@ int lbm_slab_pressure_start_finish(lbm_slab_pressure* sl, double* post, double* 
   return rc;
 }
 
+// ---- KBC start-up (ulbm_poiseuille.cpp:85-139 on the initial state: adve_f as given, HELD moments m0 [R][C], m1 [2][R][C]
+// of the slab's owned rows).  Across the pressure seam travel the 2 D rows next to it and their moments (12 planes);
+// across ordinary seams nothing is needed (the message is the pre-collision halo, unused).  The collision with held
+// moments is not node-local in what it needs (the moments of ghost rows live on the neighbour), so ghost rows of `post`
+// are NOT current afterwards: exchange complete halos of `post` (LBM_HALO_FULL(2)) over the ordinary seams before the
+// first block -- lbm_ring_pressure_start_kbc does.
+static int rows_copy_plane(double* dst, const double* src, int n_rows, int C, hipStream_t st) {
+  LBM_CHECK_HIP(hipMemcpyAsync(dst, src, (size_t)n_rows * C * sizeof(double), hipMemcpyDeviceToDevice, st));
+  return LBM_OK;
+}
+
+int lbm_slab_pressure_start_pack_kbc(lbm_slab_pressure* sl, const double* pre, const double* m0, const double* m1,
+                                     double* send_prev, double* send_next, lbm_stream_t s) {
+  LBM_REQUIRE(sl && pre && m0 && m1 && send_prev && send_next, "lbm_slab_pressure_start_pack_kbc: NULL argument");
+  LBM_REQUIRE(sl->model == LBM_MODEL_KBC, "lbm_slab_pressure_start_pack_kbc: not a KBC slab");
+  const int R = sl->g.R, C = sl->g.C, D = sl->D, full = LBM_HALO_FULL(D);
+  hipStream_t st = as_stream(s);
+  const lbm_geom mg = msg_geom(2 * D, C);
+  const size_t n = (size_t)R * C, rows = (size_t)2 * D * C;
+  int rc = LBM_OK;
+  if (sl->first) {
+    rc = lbm_rows_copy(send_prev, &mg, 0, pre, &sl->g, 0, 2 * D, s);
+    if (!rc) rc = rows_copy_plane(send_prev + 9 * rows, m0, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(send_prev + 10 * rows, m1, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(send_prev + 11 * rows, m1 + n, 2 * D, C, st);
+  } else {
+    rc = lbm_halo_pack(send_prev, pre, &sl->g, full, 0, s);
+  }
+  if (rc) return rc;
+  if (sl->last) {
+    const size_t o = (size_t)(R - 2 * D) * C;
+    rc = lbm_rows_copy(send_next, &mg, 0, pre, &sl->g, R - 2 * D, 2 * D, s);
+    if (!rc) rc = rows_copy_plane(send_next + 9 * rows, m0 + o, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(send_next + 10 * rows, m1 + o, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(send_next + 11 * rows, m1 + n + o, 2 * D, C, st);
+  } else {
+    rc = lbm_halo_pack(send_next, pre, &sl->g, full, 1, s);
+  }
+  return rc;
+}
+
+int lbm_slab_pressure_start_finish_kbc(lbm_slab_pressure* sl, double* post, double* pre, const double* m0, const double* m1,
+                                       const double* recv_prev, const double* recv_next, lbm_stream_t s) {
+  LBM_REQUIRE(sl && post && pre && post != pre && m0 && m1 && recv_prev && recv_next, "lbm_slab_pressure_start_finish_kbc: bad argument");
+  LBM_REQUIRE(sl->model == LBM_MODEL_KBC, "lbm_slab_pressure_start_finish_kbc: not a KBC slab");
+  const int R = sl->g.R, C = sl->g.C, D = sl->D, G = sl->g.ghost;
+  hipStream_t st = as_stream(s);
+  // the owned rows on their held moments (kbc::collide with the driver's m0, m1, ulbm.cpp:91-126)
+  const lbm_geom own{R, C, 0, plane_of(sl->g)};
+  int rc = lbm_kbc_collide_first(post + (size_t)G * C, pre + (size_t)G * C, m0, m1, &own, nullptr, &sl->kprm, s);
+  if (rc || (!sl->first && !sl->last)) return rc;
+  // small lattice, pre-collision: rows [0, 2D) of the domain, then rows [Rg - 2D, Rg); its held moments likewise
+  const lbm_geom mg = msg_geom(2 * D, C);
+  const size_t n = (size_t)R * C, rows = (size_t)2 * D * C, sn = (size_t)4 * D * C;
+  double* sp = sl->slat[sl->scur];
+  if (sl->first) {
+    rc = lbm_rows_copy(sp, &sl->sg, 0, pre, &sl->g, 0, 2 * D, s);
+    if (!rc) rc = lbm_rows_copy(sp, &sl->sg, 2 * D, recv_prev, &mg, 0, 2 * D, s);
+    if (!rc) rc = rows_copy_plane(sl->sm0, m0, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1, m1, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1 + sn, m1 + n, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm0 + rows, recv_prev + 9 * rows, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1 + rows, recv_prev + 10 * rows, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1 + sn + rows, recv_prev + 11 * rows, 2 * D, C, st);
+  } else {
+    const size_t o = (size_t)(R - 2 * D) * C;
+    rc = lbm_rows_copy(sp, &sl->sg, 2 * D, pre, &sl->g, R - 2 * D, 2 * D, s);
+    if (!rc) rc = lbm_rows_copy(sp, &sl->sg, 0, recv_next, &mg, 0, 2 * D, s);
+    if (!rc) rc = rows_copy_plane(sl->sm0 + rows, m0 + o, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1 + rows, m1 + o, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1 + sn + rows, m1 + n + o, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm0, recv_next + 9 * rows, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1, recv_next + 10 * rows, 2 * D, C, st);
+    if (!rc) rc = rows_copy_plane(sl->sm1 + sn, recv_next + 11 * rows, 2 * D, C, st);
+  }
+  double* so = sl->slat[sl->scur ^ 1];
+  if (!rc) rc = lbm_kbc_collide_first(so, sp, sl->sm0, sl->sm1, &sl->sg, &sl->bc_seam, &sl->kprm, s);  // incl. the pressure rows (:36-58)
+  if (rc) return rc;
+  sl->scur ^= 1;
+  const lbm_geom dg = msg_geom(D, C);
+  if (sl->first) {
+    rc = lbm_rows_copy(post, &sl->g, 0, so, &sl->sg, 0, 2 * D, s);
+    if (!rc) rc = lbm_rows_copy(sl->stash, &dg, 0, so, &sl->sg, 2 * D, D, s);
+  } else {
+    rc = lbm_rows_copy(post, &sl->g, R - 2 * D, so, &sl->sg, 2 * D, 2 * D, s);
+    if (!rc) rc = lbm_rows_copy(sl->stash, &dg, 0, so, &sl->sg, D, D, s);
+  }
+  return rc;
+}
+
 // one block of D steps, phase A: dst from src on the owned rows, both outgoing messages packed
 int lbm_slab_pressure_block_compute(lbm_slab_pressure* sl, double* dst, const double* src, double* send_prev,
                                     double* send_next, lbm_stream_t s) {
@@ -194,8 +318,10 @@ int lbm_slab_pressure_block_compute(lbm_slab_pressure* sl, double* dst, const do
       if (!rc) rc = lbm_rows_copy(sp, &sl->sg, D, sl->stash, &dg, 0, D, sl->aux);
     }
     for (int k = 0; k < D && !rc; ++k) {
-      rc = lbm_bgk_stream_collide(sl->slat[sl->scur ^ 1], sl->slat[sl->scur], &sl->sg, &sl->bc_seam, &sl->prm, 0, 4 * D, nullptr,
-                                  nullptr, sl->aux);
+      rc = sl->model == LBM_MODEL_KBC
+               ? lbm_kbc_stream_collide(sl->slat[sl->scur ^ 1], sl->slat[sl->scur], &sl->sg, &sl->bc_seam, &sl->kprm, 0, 4 * D, nullptr, nullptr, sl->aux)
+               : lbm_bgk_stream_collide(sl->slat[sl->scur ^ 1], sl->slat[sl->scur], &sl->sg, &sl->bc_seam, &sl->prm, 0, 4 * D, nullptr,
+                                        nullptr, sl->aux);
       sl->scur ^= 1;
     }
     if (rc) return rc;
@@ -207,7 +333,8 @@ int lbm_slab_pressure_block_compute(lbm_slab_pressure* sl, double* dst, const do
   }
   // far rows: the D-step window in the reference operation order (lattices with pressure rows keep it on every path)
   const int r0 = sl->first ? D : 0, r1 = sl->last ? R - D : R;
-  rc = bgk_stream_collide_xn_ref(dst, src, &sl->g, &sl->bc_far, &sl->prm, D, r0, r1, st);
+  rc = sl->model == LBM_MODEL_KBC ? kbc_stream_collide_x2_ref(dst, src, &sl->g, &sl->bc_far, &sl->kprm, r0, r1, st)
+                                  : bgk_stream_collide_xn_ref(dst, src, &sl->g, &sl->bc_far, &sl->prm, D, r0, r1, st);
   if (rc) return rc;
   if (end) LBM_CHECK_HIP(hipStreamWaitEvent(st, sl->ev_join, 0));
   const lbm_geom dg = msg_geom(D, C);

@@ -142,6 +142,27 @@ def main():
         out["P"] = lat[cur][:, D:R + D].cpu().numpy()
         lib.ring_destroy(ring)
         lib.slab_pressure_destroy(h)
+    elif case == "pressure_kbc":
+        R, W, D = cfg["R"], cfg["W"], 2
+        H = R * n
+        geom = pylbm.Geom(R, W, D)
+        bc, prm = struct(pylbm.Bc, "bc"), struct(pylbm.KbcParams, "prm")
+        m0, m1 = load("m0")[rank * R:(rank + 1) * R].contiguous(), load("m1")[:, rank * R:(rank + 1) * R].contiguous()
+        h = ct.c_void_p()
+        lib.slab_pressure_create_kbc(ct.byref(h), ct.byref(geom), rank * R, H, ct.byref(bc), ct.byref(prm))
+        pre = zeros(R, D, W)              # the driver starts from adve_f = 0 (ulbm_poiseuille.cpp:85-86)
+        lat = [zeros(R, D, W), zeros(R, D, W)]
+        ring = make_ring(geom, 1)
+        lib.ring_pressure_start_kbc(ring, h, _ptr(lat[0]), _ptr(pre), _ptr(m0), _ptr(m1), None)
+        cur = 0
+        for _ in range(cfg["blocks"]):
+            lib.ring_bgk_block_pressure(ring, h, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), None)
+            cur ^= 1
+        torch.cuda.synchronize()
+        lib.ring_status(ring)
+        out["P"] = lat[cur][:, D:R + D].cpu().numpy()
+        lib.ring_destroy(ring)
+        lib.slab_pressure_destroy(h)
     else:
         raise SystemExit(f"unknown case {case}")
     np.savez(os.path.join(work, f"out_{rank}.npz"), **out)

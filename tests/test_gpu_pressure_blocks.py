@@ -186,3 +186,85 @@ def test_pressure_rows_over_emulated_slabs_equal_single_block(lib, case, n_slabs
     for h in slabs:
         lib.slab_pressure_destroy(h)
     assert bits_equal(got, want), (case, n_slabs, D, ulp_diff(got, want))
+
+
+@pytest.mark.parametrize("n_slabs", [2, 3])
+def test_kbc_pressure_rows_over_emulated_slabs_equal_single_block(lib, n_slabs):
+    """ulbm_poiseuille (KBC + pressure rows + bounce-back columns, start from adve_f = 0 on held moments,
+    test/ulbm_poiseuille.cpp:36-58, :85-139) over a periodic ring of slabs in 2-step blocks: the end slabs replicate the
+    small seam lattice (its first iteration on the held moments of both sides), far rows through the reference-order
+    2-step window; start-up + 4 blocks == the single block stepped one step per launch, bit for bit."""
+    import ctypes as ct
+    from gpu_util import dev, download_aos, upload_soa
+    from pylbm import _ptr
+    R, W, D, nb = 64, 128, 2, 4
+    H = R * n_slabs
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    rin = 3.0 * (H - 1) * (8.0 * nu * 0.05 / (W * W)) + 1.0
+    bc = pylbm.Bc(col_lo=pylbm.EDGE_BOUNCE_BACK, col_hi=pylbm.EDGE_BOUNCE_BACK, pressure_rows=1, rho_inlet=rin, rho_outlet=1.0)
+    prm = pylbm.KbcParams(s2)
+    rng = np.random.default_rng(3)
+    m0 = 1.0 + 0.001 * rng.standard_normal((H, W))          # held moments that differ from row to row: a wrong row shows
+    m1 = 0.001 * rng.standard_normal((H, W, 2))
+    f0 = np.zeros((H, W, 9))
+    want = run(lib, pylbm.MODEL_KBC, H, W, prm, bc, f0, 1 + nb * D, 1, (m0, m1))
+    d = dev()
+    geom = pylbm.Geom(R, W, D)
+    lib.raw.lbm_slab_pressure_msg_doubles.restype = ct.c_longlong
+    slabs = []
+    for s_ in range(n_slabs):
+        h = ct.c_void_p()
+        lib.slab_pressure_create_kbc(ct.byref(h), ct.byref(geom), s_ * R, H, ct.byref(bc), ct.byref(prm))
+        slabs.append(h)
+    m0d = torch.from_numpy(m0).to(d)
+    m1d = torch.from_numpy(np.ascontiguousarray(np.moveaxis(m1, -1, 0))).to(d)
+    pre = [torch.zeros((9, R + 2 * D, W), dtype=torch.float64, device=d) for _ in range(n_slabs)]
+    lat = [[torch.zeros((9, R + 2 * D, W), dtype=torch.float64, device=d) for _ in range(2)] for _ in range(n_slabs)]
+    sm0 = [m0d[s_ * R:(s_ + 1) * R].contiguous() for s_ in range(n_slabs)]
+    sm1 = [m1d[:, s_ * R:(s_ + 1) * R].contiguous() for s_ in range(n_slabs)]
+
+    def exchange(pack, finish, start):
+        bufs = []
+        for s_, h in enumerate(slabs):
+            n = [int(lib.raw.lbm_slab_pressure_msg_doubles(h, side, start)) for side in (0, 1)]
+            b = dict(sp=torch.zeros(n[0], dtype=torch.float64, device=d), rp=torch.zeros(n[0], dtype=torch.float64, device=d),
+                     sn=torch.zeros(n[1], dtype=torch.float64, device=d), rn=torch.zeros(n[1], dtype=torch.float64, device=d))
+            bufs.append(b)
+            pack(s_, h, b)
+        torch.cuda.synchronize()
+        for s_ in range(n_slabs):
+            nx = (s_ + 1) % n_slabs
+            assert bufs[s_]["sn"].numel() == bufs[nx]["rp"].numel() and bufs[nx]["sp"].numel() == bufs[s_]["rn"].numel()
+            bufs[nx]["rp"].copy_(bufs[s_]["sn"])
+            bufs[s_]["rn"].copy_(bufs[nx]["sp"])
+        torch.cuda.synchronize()
+        for s_, h in enumerate(slabs):
+            finish(s_, h, bufs[s_])
+        torch.cuda.synchronize()
+
+    exchange(lambda s_, h, b: lib.slab_pressure_start_pack_kbc(h, _ptr(pre[s_]), _ptr(sm0[s_]), _ptr(sm1[s_]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+             lambda s_, h, b: lib.slab_pressure_start_finish_kbc(h, _ptr(lat[s_][0]), _ptr(pre[s_]), _ptr(sm0[s_]), _ptr(sm1[s_]),
+                                                                 _ptr(b["rp"]), _ptr(b["rn"]), None), 1)
+    # complete halos of the post-collision state over every seam of the ring (what lbm_ring_pressure_start_kbc ends with)
+    full = 100 + D
+    msg = torch.empty(lib.raw.lbm_halo_rows(full) * W, dtype=torch.float64, device=d)
+    for s_ in range(n_slabs):
+        nx = (s_ + 1) % n_slabs
+        lib.halo_pack(_ptr(msg), _ptr(lat[s_][0]), ct.byref(geom), full, 1, None)
+        lib.halo_unpack(_ptr(lat[nx][0]), _ptr(msg), ct.byref(geom), full, 0, None)
+        lib.halo_pack(_ptr(msg), _ptr(lat[nx][0]), ct.byref(geom), full, 0, None)
+        lib.halo_unpack(_ptr(lat[s_][0]), _ptr(msg), ct.byref(geom), full, 1, None)
+    cur = 0
+    for _ in range(nb):
+        exchange(lambda s_, h, b: lib.slab_pressure_block_compute(h, _ptr(lat[s_][cur ^ 1]), _ptr(lat[s_][cur]), _ptr(b["sp"]), _ptr(b["sn"]), None),
+                 lambda s_, h, b: lib.slab_pressure_block_finish(h, _ptr(lat[s_][cur ^ 1]), _ptr(b["rp"]), _ptr(b["rn"]), None), 0)
+        cur ^= 1
+    P = torch.cat([lat[s_][cur][:, D:R + D] for s_ in range(n_slabs)], dim=1).contiguous()
+    out = torch.empty_like(P)
+    flat = pylbm.Geom(H, W, 0)
+    lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc), None)
+    got = download_aos(lib, out)
+    for h in slabs:
+        lib.slab_pressure_destroy(h)
+    assert bits_equal(got, want), (n_slabs, ulp_diff(got, want))

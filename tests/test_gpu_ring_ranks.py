@@ -253,6 +253,38 @@ def test_pressure_rows_across_processes_equal_one_block(lib, tmp_path, case, n, 
     assert bits_equal(got, want), (case, n, D, ulp_diff(got, want))
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_kbc_pressure_rows_across_processes_equal_one_block(lib, tmp_path, n):
+    """lbm_ring_pressure_start_kbc + lbm_ring_bgk_block_pressure on KBC slabs (ulbm_poiseuille.cpp:36-58, :85-139 over the
+    ring): held moments per rank, 12-plane start-up message across the pressure seam, 2-step blocks"""
+    R, W, nb, D = 64, 128, 4, 2
+    H = R * n
+    nu = 1e-4
+    s2 = 1.0 / (0.5 + 3.0 * nu)
+    rin = 3.0 * (H - 1) * (8.0 * nu * 0.05 / (W * W)) + 1.0
+    bc = pylbm.Bc(col_lo=pylbm.EDGE_BOUNCE_BACK, col_hi=pylbm.EDGE_BOUNCE_BACK, pressure_rows=1, rho_inlet=rin, rho_outlet=1.0)
+    prm = pylbm.KbcParams(s2)
+    rng = np.random.default_rng(4)
+    m0 = 1.0 + 0.001 * rng.standard_normal((H, W))
+    m1 = 0.001 * rng.standard_normal((H, W, 2))
+    lib.set_tuning(b"pressure_depth", 1)
+    sv = pylbm.Solver(lib, pylbm.MODEL_KBC, H, W, prm, bc=bc)
+    sv.set_f(np.zeros((H, W, 9)))
+    sv.set_moments(m0, m1)
+    sv.step(1 + nb * D)
+    want = sv.get_f()
+    sv.close()
+    lib.set_tuning(b"pressure_depth", -1)
+    outs = run_ranks(lib, tmp_path, "pressure_kbc", n, dict(R=R, W=W, blocks=nb, bc=hexof(bc), prm=hexof(prm)),
+                     dict(m0=m0, m1=np.ascontiguousarray(np.moveaxis(m1, -1, 0))))
+    P = torch.from_numpy(np.concatenate([o["P"] for o in outs], axis=1)).to(dev())
+    out = torch.empty_like(P)
+    flat = pylbm.Geom(H, W, 0)
+    lib.stream(_ptr(out), _ptr(P), ct.byref(flat), ct.byref(bc), None)
+    got = download_aos(lib, out)
+    assert bits_equal(got, want), (n, ulp_diff(got, want))
+
+
 def test_a_rank_that_never_arrives_is_reported_not_waited_for_forever(lib, tmp_path):
     """the bounded device-side wait: rank 1 of 2 maps the windows and leaves; rank 0's launches drain and
     lbm_ring_status says which neighbour failed"""
