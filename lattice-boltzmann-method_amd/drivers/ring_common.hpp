@@ -64,7 +64,7 @@ int spawn_ranks(int n, F&& run) {
     }
     if (pid < 0) {
       std::perror("fork");
-      for (pid_t k : kids) kill(k, SIGKILL);
+      for (pid_t k : kids) kill(k, SIGKILL);  // (all still our un-reaped children here)
       for (pid_t k : kids) waitpid(k, nullptr, 0);
       return 1;
     }
@@ -72,24 +72,29 @@ int spawn_ranks(int n, F&& run) {
   }
   int worst = 0;
   size_t left = kids.size();
-  bool killing = false;
+  bool killing = false, killed_hard = false;
   auto t_kill = std::chrono::steady_clock::now();
   while (left > 0) {
     int st = 0;
     pid_t k = waitpid(-1, &st, killing ? WNOHANG : 0);
     if (k > 0) {
       --left;
+      for (pid_t& o : kids)
+        if (o == k) o = -1;  // reaped: its pid may be handed to an unrelated process from now on -- never signal it again
       const int rc = WIFEXITED(st) ? WEXITSTATUS(st) : 1;
       if (rc != 0 && worst == 0) worst = rc;
       if (rc != 0 && !killing) {  // first failure: stop the survivors
         killing = true;
         t_kill = std::chrono::steady_clock::now();
         for (pid_t o : kids)
-          if (o != k) kill(o, SIGTERM);
+          if (o > 0) kill(o, SIGTERM);
       }
     } else if (k == 0) {  // survivors still running after SIGTERM
-      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_kill).count() > 5.0)
-        for (pid_t o : kids) kill(o, SIGKILL);
+      if (!killed_hard && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_kill).count() > 5.0) {
+        killed_hard = true;  // once
+        for (pid_t o : kids)
+          if (o > 0) kill(o, SIGKILL);
+      }
       std::this_thread::sleep_for(std::chrono::milliseconds(20));
     } else {
       break;  // ECHILD: nothing left to wait for
