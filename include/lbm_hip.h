@@ -321,6 +321,11 @@ int lbm_cg_solver_destroy(lbm_cg_solver* sv);
 int lbm_cg_solver_set_state(lbm_cg_solver* sv, const double* f_r, const double* f_b,
                             const double* rho_r, const double* rho_b, const double* u);
 int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps);
+/* how many two-step passes lbm_cg_solver_step has run so far.  EXPERIMENTS build only (0 otherwise): with tuning "cg_depth" = 2
+ * single blocks with the driver's walls (rows >= 128, columns >= 352, multiple of 16) advance TWO steps per pass -- every
+ * lattice row read once and written once per two steps (k_cg_two_step), the frame of the lattice through two single steps on
+ * two small band lattices; same bits as single steps, measured SLOWER than them, hence not in the default build */
+long long lbm_cg_solver_pair_launches(const lbm_cg_solver* sv);
 int lbm_cg_solver_get_state(lbm_cg_solver* sv, double* f_r, double* f_b, double* rho_r,
                             double* rho_b, double* u, double* psi, double* s_nu);
 int lbm_cg_solver_sync(lbm_cg_solver* sv);

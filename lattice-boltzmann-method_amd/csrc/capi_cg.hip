@@ -351,7 +351,19 @@ struct lbm_cg_solver {
   int cur;
   bool post;
   long steps;
+  // two steps per pass (cg_solver_step2): the frame of the lattice advances two single steps on two small lattices --
+  // row band: rows [0, HB) and [R - HB, R) x all columns; column band: all rows x columns [0, WB) and [C - WB, C)
+  double* rband[2][2];  // [buffer][colour]
+  double* cband[2][2];
+  lbm_geom rbg, cbg;
+  hipStream_t band_st;
+  hipEvent_t ev_band_fork, ev_band_join;
+  long pair_launches;
 };
+#ifdef LBM_EXPERIMENTS
+static constexpr int kCgX2RowBand = 16, kCgX2ColBand = 32;  // the frame the two-step kernel leaves out (tile-aligned)
+static constexpr int kCgX2HB = 32, kCgX2WB = 48;            // rows / columns per side the band lattices hold (valid after 2 steps: HB - 6, WB - 6)
+#endif
 
 extern "C" {
 
@@ -371,6 +383,11 @@ int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* b
   sv->cur = 0;
   sv->post = false;
   sv->steps = 0;
+  sv->pair_launches = 0;
+  sv->band_st = nullptr;
+  sv->ev_band_fork = sv->ev_band_join = nullptr;
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 2; ++k) sv->rband[b][k] = sv->cband[b][k] = nullptr;
   const size_t n = (size_t)g->R * g->C;
   sv->g.plane_stride = (long long)n + lbm_default_plane_pad(g->R, g->C);
   const size_t lat_bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
@@ -395,8 +412,15 @@ int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* b
 int lbm_cg_solver_destroy(lbm_cg_solver* sv) {
   if (!sv) return LBM_OK;
   for (double* p : {sv->lat[0][0], sv->lat[0][1], sv->lat[1][0], sv->lat[1][1], sv->rho_r, sv->rho_b,
-                    sv->u, sv->psi, sv->snu, sv->stage})
+                    sv->u, sv->psi, sv->snu, sv->stage, sv->rband[0][0], sv->rband[0][1], sv->rband[1][0], sv->rband[1][1],
+                    sv->cband[0][0], sv->cband[0][1], sv->cband[1][0], sv->cband[1][1]})
     if (p) (void)hipFree(p);
+  if (sv->band_st) {
+    (void)hipStreamSynchronize(sv->band_st);
+    (void)hipStreamDestroy(sv->band_st);
+  }
+  if (sv->ev_band_fork) (void)hipEventDestroy(sv->ev_band_fork);
+  if (sv->ev_band_join) (void)hipEventDestroy(sv->ev_band_join);
   delete sv;
   return LBM_OK;
 }
@@ -423,9 +447,120 @@ int lbm_cg_solver_set_state(lbm_cg_solver* sv, const double* f_r, const double* 
   return LBM_OK;
 }
 
+#ifdef LBM_EXPERIMENTS
+// ---- two steps per pass ---------------------------------------------------------------------------------------------------
+// k_cg_two_step (cg_fused.hpp) on the nodes whose two-step dependency cone holds plain nodes only -- rows [16, R - 16) x
+// columns [32, C - 32) --, and the frame around them through TWO single steps of the ordinary one-launch kernel on two small
+// lattices: a row band (rows [0, 32) then [R - 32, R): its first / last rows ARE the walls, the artificial seam in its middle
+// spoils 3 rows per side and step, rows [0, 16) and [48, 64) are copied back) and a column band (columns [0, 48) then
+// [C - 48, C): its first / last columns are the pair the driver's same-row column copy couples, :517-523).  The band chain
+// runs on a helper stream beside the big launch.  Same kernels per node as two single steps: same bits.
+static bool cg_two_step_applies(const lbm_cg_solver* sv) {
+  lbm_bc d;
+  lbm_cg_default_bc(&d);
+  const lbm_bc& b = sv->bc;
+  const bool walls = b.row_lo == d.row_lo && b.row_hi == d.row_hi && b.col_lo == d.col_lo && b.col_hi == d.col_hi && !b.pressure_rows;
+  const long long plane = sv->g.plane_stride;
+  return walls && sv->g.ghost == 0 && sv->g.C % 16 == 0 && plane % 16 == 0 && sv->g.R >= 2 * kCgX2HB + 64 && sv->g.C >= 2 * kCgX2WB + 256;
+}
+
+static int cg_two_step_prepare(lbm_cg_solver* sv) {
+  if (sv->band_st) return LBM_OK;
+  const int R = sv->g.R, C = sv->g.C;
+  sv->rbg = lbm_geom{2 * kCgX2HB, C, 0, (long long)2 * kCgX2HB * C + 1088};
+  sv->cbg = lbm_geom{R, 2 * kCgX2WB, 0, (long long)R * 2 * kCgX2WB + 1088};
+  for (int b = 0; b < 2; ++b)
+    for (int k = 0; k < 2; ++k) {
+      LBM_CHECK_HIP(hipMalloc(&sv->rband[b][k], (size_t)sv->rbg.plane_stride * 9 * sizeof(double)));
+      LBM_CHECK_HIP(hipMalloc(&sv->cband[b][k], (size_t)sv->cbg.plane_stride * 9 * sizeof(double)));
+    }
+  LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_band_fork, hipEventDisableTiming));
+  LBM_CHECK_HIP(hipEventCreateWithFlags(&sv->ev_band_join, hipEventDisableTiming));
+  LBM_CHECK_HIP(hipStreamCreateWithFlags(&sv->band_st, hipStreamNonBlocking));
+  return LBM_OK;
+}
+
+static int cg_solver_step2(lbm_cg_solver* sv) {
+  int rc = cg_two_step_prepare(sv);
+  if (rc) return rc;
+  const int R = sv->g.R, C = sv->g.C, HB = kCgX2HB, WB = kCgX2WB;
+  double** src = sv->lat[sv->cur];
+  double** dst = sv->lat[sv->cur ^ 1];
+  hipStream_t st = sv->st, bs = sv->band_st;
+  LBM_CHECK_HIP(hipEventRecord(sv->ev_band_fork, st));
+  LBM_CHECK_HIP(hipStreamWaitEvent(bs, sv->ev_band_fork, 0));
+  // ---- the frame: copy in, two single steps, on the helper stream ----
+  for (int k = 0; k < 2 && !rc; ++k) {
+    rc = box_copy(sv->rband[0][k], sv->rbg, 0, 0, src[k], sv->g, 0, 0, HB, C, bs);
+    if (!rc) rc = box_copy(sv->rband[0][k], sv->rbg, HB, 0, src[k], sv->g, R - HB, 0, HB, C, bs);
+    if (!rc) rc = box_copy(sv->cband[0][k], sv->cbg, 0, 0, src[k], sv->g, 0, 0, R, WB, bs);
+    if (!rc) rc = box_copy(sv->cband[0][k], sv->cbg, 0, WB, src[k], sv->g, 0, C - WB, R, WB, bs);
+  }
+  for (int t = 0; t < 2 && !rc; ++t) {
+    rc = lbm_cg_step_fused(sv->rband[t ^ 1][0], sv->rband[t ^ 1][1], sv->rband[t][0], sv->rband[t][1], &sv->rbg, &sv->bc, &sv->prm, 0,
+                           2 * HB, nullptr, nullptr, nullptr, nullptr, nullptr, bs);
+    if (!rc) rc = lbm_cg_step_fused(sv->cband[t ^ 1][0], sv->cband[t ^ 1][1], sv->cband[t][0], sv->cband[t][1], &sv->cbg, &sv->bc, &sv->prm,
+                                    0, R, nullptr, nullptr, nullptr, nullptr, nullptr, bs);
+  }
+  if (rc) return rc;
+  // ---- the inner rectangle: two steps in one pass, on the caller's stream ----
+  {
+    constexpr int Wv = 4, S = 64 * Wv - 2 * CG_X2_EDGE;
+    const Geom g = make_geom(sv->g);
+    const CgFast cf = make_cg_fast(make_cg_consts(sv->prm));
+    const int ra = kCgX2RowBand, rb = R - kCgX2RowBand, ca = kCgX2ColBand, cb = C - kCgX2ColBand;
+    const int win0 = (ca - CG_X2_EDGE) / 16 * 16;
+    const int bstrips = (cb - (win0 + CG_X2_EDGE) + S - 1) / S;
+    const int mode = tuning("cg_x2_unroll", 0) & 3;
+    const void* kfn = mode == 0 ? (const void*)k_cg_two_step<Wv, 0> : mode == 1 ? (const void*)k_cg_two_step<Wv, 1>
+                    : mode == 2 ? (const void*)k_cg_two_step<Wv, 2> : (const void*)k_cg_two_step<Wv, 3>;
+    int rpc = tuning("cg_rows2", 0);
+    if (rpc <= 0) {
+      const long slots = sw_wave_slots(kfn, 64 * Wv);
+      rpc = slots > 0 ? sw_pick_rows(rb - ra, bstrips * Wv, 8, slots) : 256;  // 14 warm-up rows ~ a depth-8 window's
+    }
+    if (rpc > rb - ra) rpc = rb - ra;
+    const int chunks = (rb - ra + rpc - 1) / rpc;
+#define LBM_CG_X2(M) LBM_KLAUNCH((k_cg_two_step<Wv, M>), dim3(bstrips * chunks), dim3(64 * Wv), 0, st, dst[0], dst[1], src[0], src[1], g, cf, ra, rb, ca, cb, rpc, bstrips, win0)
+    if (mode == 0) LBM_CG_X2(0); else if (mode == 1) LBM_CG_X2(1); else if (mode == 2) LBM_CG_X2(2); else LBM_CG_X2(3);
+#undef LBM_CG_X2
+    LBM_CHECK_LAUNCH();
+  }
+  // ---- the frame's valid part into the new lattice (behind the big launch: the regions are disjoint, but one stream writes) ----
+  LBM_CHECK_HIP(hipEventRecord(sv->ev_band_join, bs));
+  LBM_CHECK_HIP(hipStreamWaitEvent(st, sv->ev_band_join, 0));
+  for (int k = 0; k < 2 && !rc; ++k) {
+    rc = box_copy(dst[k], sv->g, 0, 0, sv->rband[0][k], sv->rbg, 0, 0, kCgX2RowBand, C, st);
+    if (!rc) rc = box_copy(dst[k], sv->g, R - kCgX2RowBand, 0, sv->rband[0][k], sv->rbg, 2 * HB - kCgX2RowBand, 0, kCgX2RowBand, C, st);
+    if (!rc) rc = box_copy(dst[k], sv->g, 0, 0, sv->cband[0][k], sv->cbg, 0, 0, R, kCgX2ColBand, st);
+    if (!rc) rc = box_copy(dst[k], sv->g, 0, C - kCgX2ColBand, sv->cband[0][k], sv->cbg, 0, 2 * WB - kCgX2ColBand, R, kCgX2ColBand, st);
+  }
+  if (rc) return rc;
+  sv->cur ^= 1;
+  sv->steps += 2;
+  ++sv->pair_launches;
+  return LBM_OK;
+}
+
+#endif  // LBM_EXPERIMENTS
+
+long long lbm_cg_solver_pair_launches(const lbm_cg_solver* sv) { return sv ? sv->pair_launches : -1; }
+
 int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps) {
   LBM_REQUIRE(sv && n_steps >= 0, "lbm_cg_solver_step: bad argument");
+  const bool fused = sv->prm.form == LBM_FORM_DEFAULT ? tuning("cg_fused", 1) != 0 : sv->prm.form == LBM_FORM_REASSOCIATED;
+  (void)fused;
   for (int i = 0; i < n_steps; ++i) {
+#ifdef LBM_EXPERIMENTS
+    // "cg_depth" = 2 (opt-in): two steps per pass while at least three remain (the LAST step of a call writes the observable
+    // fields: a single step).  Bit-identical and slower: 13.6 k against 15.7-16.1 k MLUPS at 8192 x 2048.
+    if (fused && tuning("cg_depth", 1) >= 2 && cg_two_step_applies(sv) && sv->post && n_steps - i >= 3) {
+      int rc = cg_solver_step2(sv);
+      if (rc) return rc;
+      ++i;
+      continue;
+    }
+#endif
     double** src = sv->lat[sv->cur];
     double** dst = sv->lat[sv->cur ^ 1];
     int rc;

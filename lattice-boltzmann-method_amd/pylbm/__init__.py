@@ -99,6 +99,8 @@ def load_library(path=LIB_PATH):
     lib.lbm_default_plane_pad.restype = ct.c_longlong
     lib.lbm_solver_block_launches.restype = ct.c_longlong
     lib.lbm_slab_ibm_msg_doubles.restype = ct.c_longlong
+    lib.lbm_cg_solver_pair_launches.restype = ct.c_longlong
+    lib.lbm_slab_pressure_msg_doubles.restype = ct.c_longlong
     return lib
 
 

@@ -397,3 +397,38 @@ def test_differential_facade_vs_reference_golden(lib, oracle, tmp_path):
         assert relerr(dx, g[kx]) < 1e-14 and relerr(dy, g[ky]) < 1e-14
         assert bits_equal(dx, oracle.diff_x(psi)) and bits_equal(dy, oracle.diff_y(psi))
         assert bits_equal(gr[..., 0], dx) and bits_equal(gr[..., 1], dy)   # grad = stack(x, y), differential.cpp:35-39
+
+
+@pytest.mark.parametrize("R,C", [(200, 384), (131, 352), (416, 1040)])
+def test_cg_two_steps_per_pass_equal_single_steps(lib, oracle, R, C):
+    """lbm_cg_solver_step advances TWO steps per pass on single blocks with the driver's walls (k_cg_two_step on the inner
+    rectangle: level 1's post-collision populations stay in LDS, level 2 streams them from there; the frame through two
+    single steps on the row / column band lattices).  Same kernels per node: the same BITS as one step per launch
+    ("cg_depth" = 1), chunk heights that do and do not divide the rows, and the oracle within the fused tolerance."""
+    if not lib.raw.lbm_build_has_experiments():
+        pytest.skip("the two-step pass is bit-identical but slower: an experiment (make -C lattice-boltzmann-method_amd/csrc EXPERIMENTS=1)")
+    po = pyoracle.cg_params(R, C)
+    s0 = oracle.cg_init(po)
+    res = {}
+    try:
+        for depth, rows in ((1, 0), (2, 0), (2, 23), (2, 64)):
+            lib.set_tuning(b"cg_depth", depth)
+            lib.set_tuning(b"cg_rows2", rows if rows else -1)
+            sv = pylbm.CgSolver(lib, R, C, pylbm.cg_params())
+            sv.set_state(s0["f_r"], s0["f_b"], s0["rho_r"], s0["rho_b"], s0["u"])
+            sv.step(4)          # 1 collide-first + 1 pair + 1 single
+            sv.step(9)          # 4 pairs + the last step single (it writes the fields)
+            res[(depth, rows)] = sv.get_state()
+            pairs = lib.raw.lbm_cg_solver_pair_launches(sv.h)
+            assert pairs == (0 if depth == 1 else 1 + 4), (depth, pairs)
+            sv.close()
+    finally:
+        lib.set_tuning(b"cg_depth", -1)
+        lib.set_tuning(b"cg_rows2", -1)
+    ref = res[(1, 0)]
+    for key, st in res.items():
+        for name in ("f_r", "f_b", "rho_r", "rho_b", "u", "psi", "s_nu"):
+            assert bits_equal(st[name], ref[name]), (key, name, ulp_diff(st[name], ref[name]))
+    want = oracle.cg_steps(po, s0, 13)
+    for name in ("f_r", "f_b", "rho_r", "rho_b", "u"):
+        assert relerr(ref[name], want[name]) < 1e-11, (name, relerr(ref[name], want[name]))
