@@ -1,5 +1,6 @@
 // C ABI, part 1: status, device memory/stream/event helpers, layout converters and the
 // seven unfused solver:: operators (parity surface, not the hot path).
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <cstdlib>
@@ -47,11 +48,27 @@ static void tuning_from_env() {
   }
 }
 
+// Launch paths read 6-10 keys per launch: the table itself (a map under a mutex) is consulted only when lbm_set_tuning has
+// run since this thread last looked the key up -- otherwise the answer comes from a small thread-local cache keyed by the
+// call site's string literal (pointer identity; a version counter invalidates every cache at once).
+static std::atomic<unsigned> g_tune_version{1};
+
 int tuning(const char* key, int dflt) {
+  struct Slot {
+    const char* key;
+    unsigned version;
+    int value;
+    bool present;
+  };
+  thread_local Slot cache[128] = {};
+  Slot& sl = cache[(reinterpret_cast<uintptr_t>(key) >> 3) & 127];
+  const unsigned ver = g_tune_version.load(std::memory_order_acquire);
+  if (sl.key == key && sl.version == ver) return sl.present ? sl.value : dflt;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   tuning_from_env();
   auto it = g_tune.find(key);
-  return it == g_tune.end() ? dflt : it->second;
+  sl = Slot{key, ver, it == g_tune.end() ? 0 : it->second, it != g_tune.end()};
+  return sl.present ? sl.value : dflt;
 }
 
 // ---- layout converters -------------------------------------------------------------------
@@ -418,11 +435,19 @@ int lbm_event_elapsed_ms(float* ms, void* start, void* stop) {
 int lbm_set_tuning(const char* key, int value) {
   LBM_REQUIRE(key, "lbm_set_tuning: NULL key");
   std::lock_guard<std::mutex> lk(g_tune_mu);
+  tuning_from_env();
   if (value < 0) g_tune.erase(key);  // back to the built-in default
   else g_tune[key] = value;
+  g_tune_version.fetch_add(1, std::memory_order_release);
   return LBM_OK;
 }
-int lbm_get_tuning(const char* key) { return key ? tuning(key, 0) : 0; }
+int lbm_get_tuning(const char* key) {  // (a caller's buffer, not a literal of this library: straight to the table)
+  if (!key) return 0;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  tuning_from_env();
+  auto it = g_tune.find(key);
+  return it == g_tune.end() ? 0 : it->second;
+}
 
 int lbm_build_has_experiments(void) {
 #ifdef LBM_EXPERIMENTS

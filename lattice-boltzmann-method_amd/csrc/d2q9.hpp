@@ -639,8 +639,13 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
       if (g.ghost) rr[k] = rr[k] < -g.ghost ? -g.ghost : (rr[k] > g.R + g.ghost - 1 ? g.R + g.ghost - 1 : rr[k]);
       else rr[k] = rr[k] < 0 ? rr[k] + g.R : (rr[k] >= g.R ? rr[k] - g.R : rr[k]);
     }
+    // uniform row base (scalar registers) + this lane's 32-bit byte offset: the loads take the saddr form and no
+    // 64-bit vector address arithmetic (one v_lshl_add_u64 per access before; the KBC window is VALU-bound)
 #pragma unroll
-    for (int q = 0; q < Q; ++q) nxt[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
+    for (int q = 0; q < Q; ++q) {
+      const char* rowp = reinterpret_cast<const char*>(po + q * g.plane + g.at(rr[icx(q) + 1], 0));
+      nxt[q] = *reinterpret_cast<const double*>(rowp + (unsigned)cols[icy(q) + 1] * 8u);
+    }
   }
   // ---- level 1 ---------------------------------------------------------------------------------
   double f[Q], rho, ux, uy;
@@ -723,10 +728,10 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   // ---- store level D's row -------------------------------------------------------------------------
   const int rD = rbase + i - (D - 1);  // level D's row = level 1's row - (D-1)
   if (lane_ok && rD >= R0 && rD < R1) {
-    const long o = g.at(rD, c_out);
+    const long o = g.at(rD, 0);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      double* dst = pn + q * g.plane + o;
+      double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(pn + q * g.plane + o) + (unsigned)c_out * 8u);
       if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
       else *dst = f[q];
     }
@@ -900,8 +905,8 @@ __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const doub
   }
 }
 
-template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false, bool LDSR = false>
-__global__ __launch_bounds__(64 * WAVES, (LDSR ? 2 : (WAVES == 4 ? sw_waves_per_simd(D) : 1))) void k_stream_collide_sw(
+template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false, bool LDSR = false, bool LOOSE = false>
+__global__ __launch_bounds__(64 * WAVES, (LDSR ? 2 : (WAVES == 4 && !LOOSE ? sw_waves_per_simd(D) : 1))) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
     int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0,
     int chunk_stride = 0) {
