@@ -388,6 +388,49 @@ def pmc_traffic(argv_tail, kernel_tag="k_stream_collide_sw", timeout_s=150):
     return 2.0 * out["FETCH_SIZE"], out["WRITE_SIZE"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH_SIZE x 2: gfx950)"
 
 
+def pmc_sq(argv_tail, kernel_tag="k_stream_collide_sw", timeout_s=150):
+    """one more child pass with SQ counters: share of wave cycles issuing VALU and VALU wave-instructions per launch of the
+    headline's kernel, measured in THIS run (the figure was a committed constant)"""
+    try:
+        import csv  # noqa: F401
+        rows = _pmc_run_multi(["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY"],
+                              ["--pmc-child", "headline"] + argv_tail, timeout_s)
+        acc = {}
+        for r in rows:
+            if kernel_tag in r["Kernel_Name"]:
+                acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        med = {k: statistics.median(v[2:] if len(v) > 3 else v) for k, v in acc.items()}
+        if not all(k in med for k in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU")):
+            return None
+        return {"valu_issue_frac": round(med["SQ_ACTIVE_INST_VALU"] / med["SQ_WAVE_CYCLES"], 4),
+                "valu_wave_instructions_per_launch": med["SQ_INSTS_VALU"],
+                "waitcnt_frac": round(med.get("SQ_WAIT_ANY", 0.0) / med["SQ_WAVE_CYCLES"], 4)}
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+
+
+def _pmc_run_multi(counters, child_args, timeout_s):
+    import csv
+    import glob
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        raise OSError("rocprofv3 not found")
+    d = tempfile.mkdtemp(prefix="lbm_pmc_", dir="/tmp")
+    try:
+        cmd = [exe, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + child_args
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+        rows = []
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            rows += list(csv.DictReader(open(path)))
+        if r.returncode != 0 or not rows:
+            raise OSError(f"SQ pass failed (rc {r.returncode})")
+        rows.sort(key=lambda row: int(row["Dispatch_Id"]))
+        return rows
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def pmc_between_markers(which, extra_args=(), timeout_s=240):
     """HBM bytes of EVERYTHING a secondary workload launches between its two lbm_marker kernels (the child runs
     set-up, marker, n steps, marker), per kernel name.  Returns {counter: {kernel_name: [sum_KiB, dispatches]}}."""
@@ -752,7 +795,7 @@ def main(argv=None):
         kern_ms = dev_ms / launches if a.steps % D == 0 else None
         alg_bytes = R * C * BYTES_PER_LUP * D            # algorithmic bytes one launch stands for
         traffic, traffic_src, valu = None, None, None
-        live = None
+        live, sq_live = None, None
         if world == 1 and not box.ring and D >= 2 and not a.no_pmc:
             tail = ["--rows", str(R), "--cols", str(C), "--omega", str(a.omega), "--xn", str(a.xn), "--sw-rows", str(a.sw_rows)]
             for kv in a.tune:
@@ -761,6 +804,7 @@ def main(argv=None):
                 tail += ["--plane-pad", str(a.plane_pad)]
             fb, wb_, note = pmc_traffic(tail)
             live = {"fetch_bytes": fb, "write_bytes": wb_, "note": note}
+            sq_live = pmc_sq(tail)
         try:
             tj = json.load(open(TRAFFIC_FILE))
             ent = tj.get(kernel)
@@ -791,7 +835,12 @@ def main(argv=None):
                 roof["traffic_bytes_per_update"] = round(traffic / (R * C * D), 2)
             elif D == 1:   # one step per launch: algorithmic bytes ARE the minimum traffic
                 roof["achieved"], roof["frac"] = round(alg, 1), round(alg / HBM_PEAK_GBS, 4)
-        if valu is not None:
+        if sq_live:
+            roof["valu_issue_frac"] = sq_live["valu_issue_frac"]
+            roof["valu_issue_frac_source"] = "rocprofv3 --pmc SQ pass of this run (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES)"
+            roof["waitcnt_frac"] = sq_live["waitcnt_frac"]
+            roof["valu_lane_ops_per_update"] = round(sq_live["valu_wave_instructions_per_launch"] * 64.0 / (R * C * D), 1)
+        elif valu is not None:
             roof["valu_issue_frac"] = valu
             roof["valu_issue_frac_source"] = "committed SQ pass (profiles/), not this run"
         if live:
