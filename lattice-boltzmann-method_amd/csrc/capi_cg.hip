@@ -127,6 +127,26 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     LBM_CHECK_LAUNCH();
   }
   const int sw4 = tuning("cg_strip2", 0);
+  // 31 / 32: k_cg_strip5 -- private windows, 2 / 4 adjacent strips per workgroup, a barrier every "cg_sync" rows (0: none)
+  if ((sw4 == 31 || sw4 == 32) && rc.ic0 * TC >= 8) {
+    const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
+    const int Wv = sw4 == 31 ? 2 : 4;
+    const int strips = (cb - ca + CG_SW2 - 1) / CG_SW2, groups = (strips + Wv - 1) / Wv;
+    const void* kfn = sw4 == 31 ? (psi ? (const void*)k_cg_strip5<2, true> : (const void*)k_cg_strip5<2, false>)
+                                : (psi ? (const void*)k_cg_strip5<4, true> : (const void*)k_cg_strip5<4, false>);
+    int rpc = tuning("cg_rows2", 0);
+    if (rpc <= 0) {
+      const long slots = sw_wave_slots(kfn, 64 * Wv);
+      rpc = slots > 0 ? sw_pick_rows(rb - ra, groups * Wv, 3, slots) : 64;
+    }
+    if (rpc > rb - ra) rpc = rb - ra;
+    const int chunks = (rb - ra + rpc - 1) / rpc, sync = tuning("cg_sync", 8);
+#define LBM_CG_S5(WV)                                                                                              \
+    if (psi) LBM_KLAUNCH((k_cg_strip5<WV, true>), dim3(groups * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, groups, sync); \
+    else LBM_KLAUNCH((k_cg_strip5<WV, false>), dim3(groups * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, groups, sync);
+    if (sw4 == 31) { LBM_CG_S5(2) } else { LBM_CG_S5(4) }
+#undef LBM_CG_S5
+  } else
   // 21 / 22: the lockstep block kernel (k_cg_strip4, 4 / 8 waves per block); needs line-aligned rows and planes
   if ((sw4 == 21 || sw4 == 22) && g.C % 16 == 0 && g.plane % 16 == 0 && rc.ic0 * TC >= 2 * CG_S4_EDGE) {
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
