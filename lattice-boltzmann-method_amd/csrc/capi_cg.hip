@@ -127,6 +127,35 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     LBM_CHECK_LAUNCH();
   }
   const int sw4 = tuning("cg_strip2", 0);
+  // 41 .. 45: k_cg_walk -- a workgroup of TR x WC waves walking down a strip of 64 WC - 4 columns, TR rows a step
+  if (sw4 >= 41 && sw4 <= 45 && rc.ic0 * TC >= 4) {
+    const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
+    static const int shapes[5][2] = {{4, 1}, {6, 1}, {2, 2}, {3, 2}, {2, 3}};
+    const int wtr = shapes[sw4 - 41][0], wc = shapes[sw4 - 41][1], outc = 64 * wc - 4;
+    const int strips = (cb - ca + outc - 1) / outc;
+    int rpc = tuning("cg_rows2", 0);
+    if (rpc <= 0) {  // every workgroup resident at once (12 waves per CU), no chunk shorter than 16 steps
+      const int slots = 256 * 12 / (wtr * wc);
+      int chunks = slots / strips < 1 ? 1 : slots / strips;
+      rpc = (rb - ra + chunks - 1) / chunks;
+      if (rpc < 16 * wtr) rpc = 16 * wtr;
+    }
+    rpc = (rpc + wtr - 1) / wtr * wtr;
+    if (rpc > rb - ra) rpc = rb - ra;
+    const int chunks = (rb - ra + rpc - 1) / rpc, nb = strips * chunks, grid = (nb + 7) / 8 * 8;
+    const int xo = tuning("cg_walk_xcd", 1);
+#define LBM_CG_WALK(WTR, WWC)                                                                                          \
+    if (psi) LBM_KLAUNCH((k_cg_walk<WTR, WWC, true>), dim3(grid), dim3(WTR * WWC * 64), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo); \
+    else LBM_KLAUNCH((k_cg_walk<WTR, WWC, false>), dim3(grid), dim3(WTR * WWC * 64), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo);
+    switch (sw4) {
+      case 41: LBM_CG_WALK(4, 1) break;
+      case 42: LBM_CG_WALK(6, 1) break;
+      case 43: LBM_CG_WALK(2, 2) break;
+      case 44: LBM_CG_WALK(3, 2) break;
+      default: LBM_CG_WALK(2, 3) break;
+    }
+#undef LBM_CG_WALK
+  } else
   // 31 / 32: k_cg_strip5 -- private windows, 2 / 4 adjacent strips per workgroup, a barrier every "cg_sync" rows (0: none)
   if ((sw4 == 31 || sw4 == 32) && rc.ic0 * TC >= 8) {
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;

@@ -1107,6 +1107,182 @@ __global__ __launch_bounds__(64 * W, 2) void k_cg_strip5(
   }
 }
 
+// ---- sixth form: a workgroup of TR x WC waves walks down a strip, TR rows a step ---------------------------------------
+// Between the tile kernel (16 waves per CU, moves its actual traffic at 6.4-6.7 TB/s, but reduces 22 x 36 nodes for 16 x 32
+// outputs) and the strip kernels (one row per wave and iteration, 2 waves per SIMD, a barrier or a private ring per row).
+// The block covers a window of 64 WC columns (all but 2 + 2 of them outputs) and advances TR rows per step: every thread
+// reduces ONE node of the new rows R_k + 2 .. R_k + TR + 1 into a ring of 2 TR + 4 field rows shared by the block, ONE
+// barrier, then collides one node: the one it just reduced, or -- the last two rows of threads, whose stencils reach rows
+// of the next step -- the one it reduced a step ago and parked in LDS (15 doubles).  No ring rows above or below, no extra
+// nodes: each (plane, row) is read once per strip.  The loads of step k + 1 are issued right after the barrier and arrive
+// behind the collision of step k (3 waves per SIMD: 168 VGPRs hold both).  Per-node arithmetic = the tile kernel's:
+// identical bits.
+// Addresses are a workgroup-uniform 64-bit base (scalar unit, every step) plus ONE 32-bit byte offset per thread; the
+// asm barriers keep the compiler from hoisting 36 + 18 per-thread plane addresses out of the walk loop (it spills them).
+__device__ __forceinline__ double cg_ld(const double* __restrict__ base, unsigned voff) {
+  return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + voff);
+}
+__device__ __forceinline__ void cg_st_nt(double v, double* __restrict__ base, unsigned voff) {
+  __builtin_nontemporal_store(v, reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff));
+}
+__device__ __forceinline__ void cg_st(double v, double* __restrict__ base, unsigned voff) {
+  *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff) = v;
+}
+
+template <int TR, int WC, bool WITH_FIELDS>
+__global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
+    int rows_per_chunk, int strips, int n_blocks, int xcd_order) {
+#pragma clang fp contract(on)
+  static_assert(TR >= 2, "two rows of threads park their node for a step");
+  constexpr int LW = 64 * WC, OUTC = LW - 4, NR = 2 * TR + 4, NP = 2 * LW, KW = (4 + TR - 1) / TR;
+  __shared__ double s_psi[NR][LW], s_qx[NR][LW], s_qy[NR][LW];
+  __shared__ double s_park[2][15][NP];  // [step parity][9 colour sums, rho_r, rho_b, u_x, u_y, 1 / rho, psi][thread]
+  int blk = blockIdx.x;
+  // XCD k takes the k-th contiguous eighth of the (chunk-major, strip-minor) sequence: the column neighbours of a
+  // workgroup -- which read the same 128-byte lines at the window edges -- walk beside it behind the same L2
+  if (xcd_order) blk = (blk % 8) * ((int)gridDim.x / 8) + blk / 8;  // the launch pads the grid to a multiple of 8
+  if (blk >= n_blocks) return;
+  const int strip = blk % strips, chunk = blk / strips;
+  const int R0 = row_begin + chunk * rows_per_chunk;
+  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
+  const int n_steps = (R1 - R0 + TR - 1) / TR;
+  const int c_base = col_begin + strip * OUTC;
+  const int tr = __builtin_amdgcn_readfirstlane(threadIdx.x / LW), l_ = threadIdx.x % LW;
+  const bool parks = tr >= TR - 2;  // uniform over a wave
+  double raw_r[Q], raw_b[Q];
+  auto issue = [&](int k) {  // the populations of the node this thread reduces in step k
+    int Rk = R0 + k * TR;
+    asm volatile("" : "+s"(Rk));
+    int rn = Rk + 2 + tr;  // its row, kept inside [R0 - 2, R1 + 1]
+    rn = rn < R0 - 2 ? R0 - 2 : (rn > R1 + 1 ? R1 + 1 : rn);
+    const long o = g.at(R0 - 2, c_base - 2);
+    int l = l_;
+    asm volatile("" : "+v"(l));
+    const int c = c_base - 2 + l;
+    const int dl = (c > g.C - 2 ? g.C - 2 : c) - (c_base - 2);  // loads stay inside the lattice (such lanes feed nothing stored)
+    const unsigned v = (unsigned)((rn - (R0 - 2)) * g.C + dl) * 8u;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) raw_r[q] = cg_ld(in_r + (q * g.plane + (o - icx(q) * g.C - icy(q))), v);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) raw_b[q] = cg_ld(in_b + (q * g.plane + (o - icx(q) * g.C - icy(q))), v);
+  };
+  // The results of step k are STORED in step k + 1, behind its reduction: vmcnt counts in order, so stores issued between
+  // the prefetch and its use would make the wait for the prefetched rows a wait for the write acknowledgements as well.
+  double out_r[Q], out_b[Q], of[6];
+  bool stored = true;
+  auto flush = [&](int Rp, int l) {
+    const int m = parks ? tr - (TR - 2) : tr + 2;
+    const unsigned v_out = (unsigned)(m * g.C + l) * 8u;  // from (Rp, c_base - 2)
+    const long o_out = g.at(Rp, c_base - 2);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      cg_st_nt(out_r[q], pn_r + (q * g.plane + o_out), v_out);
+      cg_st_nt(out_b[q], pn_b + (q * g.plane + o_out), v_out);
+    }
+    if (WITH_FIELDS) {
+      const long o = mi.at(Rp, c_base - 2), oo = (long)Rp * g.C + (c_base - 2);  // diagnostics carry no ghost rows
+      cg_st(of[0], rho_r_out + o, v_out);
+      cg_st(of[1], rho_b_out + o, v_out);
+      cg_st(of[2], u_out + o, v_out);
+      cg_st(of[3], u_out + (mi.n + o), v_out);
+      cg_st(of[4], psi_out + oo, v_out);
+      cg_st(of[5], snu_out + oo, v_out);
+    }
+  };
+  issue(-KW);
+  for (int k = -KW; k < n_steps; ++k) {  // k < 0: rows R0 - 2 .. R0 + 1 only, nothing collided
+    int Rk = R0 + k * TR;
+    asm volatile("" : "+s"(Rk));
+    CgFast cfl = cf;
+    asm volatile("" : "+v"(cfl.Gr), "+v"(cfl.Gc));
+    // ... and the lane index: everything derived from it (LDS addresses, byte offsets) is recomputed per step, not carried --
+    // a carried value that spills is reloaded from scratch BEHIND the prefetched loads (vmcnt counts in order)
+    int l = l_;
+    asm volatile("" : "+v"(l));
+    const int pl = tr * LW + l - (TR - 2) * LW;
+    const bool lane_out = l >= 2 && l < LW - 2 && c_base - 2 + l < col_end;
+    const int b = ((k + KW) * TR) % NR;  // ring slot of row Rk - 2
+    double ft[Q], n6[6];
+    {
+      double psi, qx, qy;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) ft[q] = raw_b[q];
+      cg_reduce_row(raw_r, ft, cfl, n6, psi, qx, qy);
+      int sl = b + tr + 4;
+      sl -= sl >= NR ? NR : 0;
+      s_psi[sl][l] = psi;
+      s_qx[sl][l] = qx;
+      s_qy[sl][l] = qy;
+    }
+    if (parks) {
+      double(*pk)[NP] = s_park[(k + 1) & 1];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) pk[q][pl] = ft[q];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) pk[9 + q][pl] = n6[q];
+    }
+    if (!stored) flush(Rk - TR, l);
+    stored = true;
+    __syncthreads();  // the fields of rows Rk - 2 .. Rk + TR + 1 are in the ring
+    // (no second barrier: the next step's rows take the slots of rows Rk - TR - 2 .. Rk - 3, which nobody reads any more,
+    // and no wave gets two steps ahead -- it would have to pass the next barrier first)
+    if (k + 1 < n_steps) issue(k + 1);
+    const int m = parks ? tr - (TR - 2) : tr + 2;  // this thread collides row Rk + m
+    if (k >= 0 && lane_out && Rk + m < R1) {
+      if (parks) {
+        const double(*pk)[NP] = s_park[k & 1];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) ft[q] = pk[q][pl];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) n6[q] = pk[9 + q][pl];
+      }
+      int rs[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        rs[i] = b + m + i;
+        rs[i] -= rs[i] >= NR ? NR : 0;
+      }
+      constexpr double kk = 1.0 / 5040.0;
+      constexpr double a0[5] = {2 * kk * 1, 2 * kk * 32, 2 * kk * 84, 2 * kk * 32, 2 * kk * 1};
+      constexpr double a1[5] = {kk * 32, kk * 448, kk * 960, kk * 448, kk * 32};
+      const int l0 = l - 2;  // columns c - 2 .. c + 2 sit at [l0 .. l0 + 4]
+      double gx = 0.0, dxqx = 0.0;
+#pragma unroll 1
+      for (int j = 0; j < 5; ++j) {  // == cg_ddrow
+        gx += a0[j] * (s_psi[rs[4]][l0 + j] - s_psi[rs[0]][l0 + j]);
+        gx += a1[j] * (s_psi[rs[3]][l0 + j] - s_psi[rs[1]][l0 + j]);
+        dxqx += a0[j] * (s_qx[rs[4]][l0 + j] - s_qx[rs[0]][l0 + j]);
+        dxqx += a1[j] * (s_qx[rs[3]][l0 + j] - s_qx[rs[1]][l0 + j]);
+      }
+      double gy = 0.0, dyqy = 0.0;
+      int sl = rs[0];
+#pragma unroll 1
+      for (int i = 0; i < 5; ++i) {  // == cg_ddcol
+        gy += a0[i] * (s_psi[sl][l0 + 4] - s_psi[sl][l0]);
+        gy += a1[i] * (s_psi[sl][l0 + 3] - s_psi[sl][l0 + 1]);
+        dyqy += a0[i] * (s_qy[sl][l0 + 4] - s_qy[sl][l0]);
+        dyqy += a1[i] * (s_qy[sl][l0 + 3] - s_qy[sl][l0 + 1]);
+        sl = sl + 1 >= NR ? 0 : sl + 1;
+      }
+      CgNode me;
+      me.rr = n6[0]; me.rb = n6[1]; me.ux = n6[2]; me.uy = n6[3]; me.irt = n6[4]; me.psi = n6[5];
+      me.qx = 0.0;
+      me.qy = 0.0;
+      double s_nu;
+      cg_collide_values(ft, me, gx, gy, dxqx, dyqy, cfl, out_r, out_b, s_nu);
+      if (WITH_FIELDS) {
+        of[0] = me.rr; of[1] = me.rb; of[2] = me.ux; of[3] = me.uy; of[4] = me.psi; of[5] = s_nu;
+      }
+      stored = false;
+    }
+  }
+  if (!stored) flush(R0 + (n_steps - 1) * TR, l_);
+}
+
 #ifdef LBM_EXPERIMENTS  // bit-identical to two single steps and SLOWER than them: make EXPERIMENTS=1
 // ---- TWO time steps per pass (round 3) -----------------------------------------------------------------
 // The k_cg_strip4 structure with a second level on top: a workgroup of W waves walks down a line-aligned 64 W-column window

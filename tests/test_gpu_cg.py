@@ -309,7 +309,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         # per workgroup, cg_rows2 rows per chunk), the frame through the tile kernel
         cases = [(0, 64), (0, 0), (21, 40), (22, 9),                  # tile kernel split / unsplit; 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
                  (31, 40), (31, 7), (32, 9), (32, 64),                # 31 / 32: the lockstep block kernel (cg_strip2 = 21 / 22)
-                 (41, 40), (42, 9), (42, 64), (42, 33)]               # 41 / 42: adjacent strips kept loosely together (cg_strip2 = 31 / 32)
+                 (41, 40), (42, 9), (42, 64), (42, 33),               # 41 / 42: adjacent strips kept loosely together (cg_strip2 = 31 / 32)
+                 (51, 40), (51, 16), (52, 9), (52, 64), (52, 24)]     # 51 / 52: the walking tile (cg_strip2 = 41 / 42)
         if lib.raw.lbm_build_has_experiments():                       # the first two strip generations (make EXPERIMENTS=1)
             cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33)]
         for strip, rows in cases:
