@@ -461,6 +461,9 @@ class Secondary:
         import pylbm
         from pylbm import _ptr
         self.lib, self.which, self.torch = lib, which, torch
+        # placement probe: a throw-away allocation of LBM_BENCH_PREALLOC_MB before the solver's own moves its lattices to
+        # other (virtual and physical) addresses -- to tell a placement effect from a kernel effect
+        self._placement = torch.empty(int(os.environ.get("LBM_BENCH_PREALLOC_MB", "0")) << 20, dtype=torch.uint8, device=dev)
         if which == "kbc":      # config 3: ulbm_double_shear_flow.cpp:42-63 at 4096^2 (s2 = omega, nu = 1.70766666e-4)
             R = C = 4096
             self.unit = int(lib.raw.lbm_get_tuning(b"kbc_depth")) or 3
