@@ -128,7 +128,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   }
   const int sw4 = tuning("cg_strip2", 0);
   // 41 .. 45: k_cg_walk -- a workgroup of TR x WC waves walking down a strip of 64 WC - 4 columns, TR rows a step
-  if (sw4 >= 41 && sw4 <= 45 && rc.ic0 * TC >= 4) {
+  if (sw4 >= 41 && sw4 <= 45 && rc.ic0 * TC >= 4 && 9.0 * (double)g.plane * 8.0 < 4.0e9) {  // 32-bit plane offsets
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
     static const int shapes[5][2] = {{4, 1}, {6, 1}, {2, 2}, {3, 2}, {2, 3}};
     const int wtr = shapes[sw4 - 41][0], wc = shapes[sw4 - 41][1], outc = 64 * wc - 4;

@@ -1153,22 +1153,31 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
   const int c_base = col_begin + strip * OUTC;
   const int tr = __builtin_amdgcn_readfirstlane(threadIdx.x / LW), l_ = threadIdx.x % LW;
   const bool parks = tr >= TR - 2;  // uniform over a wave
+  // byte offsets of the 9 gather sources and of the 9 planes from a lattice's chunk origin: 32-bit scalars for the whole
+  // walk (the launcher keeps 9 planes under 4 GB), one v_add_u32 per access -- against 36 + 18 base addresses of 64 bits
+  // rebuilt on the scalar unit every step, which spilled SGPRs into VGPR lanes
+  unsigned goff[Q], poff[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    goff[q] = (unsigned)((q * g.plane - icx(q) * g.C - icy(q)) * 8);
+    poff[q] = (unsigned)(q * g.plane * 8);
+  }
   double raw_r[Q], raw_b[Q];
   auto issue = [&](int k) {  // the populations of the node this thread reduces in step k
     int Rk = R0 + k * TR;
     asm volatile("" : "+s"(Rk));
     int rn = Rk + 2 + tr;  // its row, kept inside [R0 - 2, R1 + 1]
     rn = rn < R0 - 2 ? R0 - 2 : (rn > R1 + 1 ? R1 + 1 : rn);
-    const long o = g.at(R0 - 2, c_base - 2);
+    const long o = g.at(R0 - 3, c_base - 3);  // one row and one column further out: goff[0 .. 8] + v >= 0
     int l = l_;
     asm volatile("" : "+v"(l));
     const int c = c_base - 2 + l;
-    const int dl = (c > g.C - 2 ? g.C - 2 : c) - (c_base - 2);  // loads stay inside the lattice (such lanes feed nothing stored)
-    const unsigned v = (unsigned)((rn - (R0 - 2)) * g.C + dl) * 8u;
+    const int dl = (c > g.C - 2 ? g.C - 2 : c) - (c_base - 3);  // loads stay inside the lattice (such lanes feed nothing stored)
+    const unsigned v = (unsigned)((rn - (R0 - 3)) * g.C + dl) * 8u;
 #pragma unroll
-    for (int q = 0; q < Q; ++q) raw_r[q] = cg_ld(in_r + (q * g.plane + (o - icx(q) * g.C - icy(q))), v);
+    for (int q = 0; q < Q; ++q) raw_r[q] = cg_ld(in_r + o, goff[q] + v);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) raw_b[q] = cg_ld(in_b + (q * g.plane + (o - icx(q) * g.C - icy(q))), v);
+    for (int q = 0; q < Q; ++q) raw_b[q] = cg_ld(in_b + o, goff[q] + v);
   };
   // The results of step k are STORED in step k + 1, behind its reduction: vmcnt counts in order, so stores issued between
   // the prefetch and its use would make the wait for the prefetched rows a wait for the write acknowledgements as well.
@@ -1180,8 +1189,8 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
     const long o_out = g.at(Rp, c_base - 2);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      cg_st_nt(out_r[q], pn_r + (q * g.plane + o_out), v_out);
-      cg_st_nt(out_b[q], pn_b + (q * g.plane + o_out), v_out);
+      cg_st_nt(out_r[q], pn_r + o_out, poff[q] + v_out);
+      cg_st_nt(out_b[q], pn_b + o_out, poff[q] + v_out);
     }
     if (WITH_FIELDS) {
       const long o = mi.at(Rp, c_base - 2), oo = (long)Rp * g.C + (c_base - 2);  // diagnostics carry no ghost rows
