@@ -369,6 +369,53 @@ def _pmc_run(counter, child_args, timeout_s):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def power_probe(run_some, seconds=1.5):
+    """Shader clock and package power WHILE the workload runs: rocm-smi polled from a thread beside `seconds` of the same
+    launches, after the timed region (a host-side query: no GPU work of its own).  These f64 kernels run into the
+    package power limit, and the clock the card then settles at -- not 2.4 GHz -- is what the timed region ran on."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    import time
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return None
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            try:
+                t = subprocess.run([smi, "-d", "0", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            c = re.search(r"sclk clock level:[^(]*\((\d+)Mhz\)", t)
+            w = re.search(r"Power \(W\):\s*([0-9.]+)", t)
+            if c and w:
+                samples.append((int(c.group(1)), float(w.group(1))))
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        run_some()
+    stop.set()
+    th.join(timeout=10)
+    cap = None
+    try:
+        t = subprocess.run([smi, "-d", "0", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"Power \(W\):\s*([0-9.]+)", t)
+        cap = float(m.group(1)) if m else None
+    except Exception:
+        pass
+    busy = [x for x in samples if x[0] > 600]   # samples that caught the card idle between batches do not count
+    if not busy:
+        return None
+    import statistics as st
+    return {"sclk_mhz": int(st.median(x[0] for x in busy)), "package_w": round(st.median(x[1] for x in busy), 1),
+            "package_limit_w": cap, "samples": len(busy),
+            "how": f"rocm-smi polled beside {seconds} s of the same launches, after the timed region"}
+
+
 def pmc_traffic(argv_tail, kernel_tag="k_stream_collide_sw", timeout_s=150):
     """HBM bytes per launch of the headline's kernel, measured NOW: two child runs of this script under
     `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE each in its own pass, as MI355X_MICROARCH.md prescribes;
@@ -562,6 +609,12 @@ def run_secondary(lib, dev, which, a):
         torch.cuda.synchronize()
         wall.append(time.perf_counter() - t0)
         devms.append(ev0.elapsed_time(ev1))
+    power = None
+    if not a.no_power:
+        def _some():
+            w.step(n)
+            torch.cuda.synchronize()
+        power = power_probe(_some, 1.0)
     w.close()
     mid = sorted(range(5), key=lambda i: wall[i])[2]
     dt, group_ms = wall[mid], devms[mid] / (n // w.unit)
@@ -575,6 +628,8 @@ def run_secondary(lib, dev, which, a):
                                         f"{w.unit} step(s), helper-stream launches included",
                         "algorithmic_bytes_per_launch": alg, "algorithmic_GBs": round(alg / (group_ms * 1e-3) / 1e9, 1),
                         "algorithmic_multiple": round(alg / (group_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if power:
+        out["roofline"]["power"] = power
     if not a.no_pmc:
         groups = PMC_GROUPS[which]
         try:
@@ -657,6 +712,7 @@ def parse_args(argv):
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks: seconds before the run is given up")
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip configs 3 / 4 / 5 after the headline")
     ap.add_argument("--secondary", default="kbc,cg,ibm", help="which secondary workloads (N = 1)")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi clock / power samples beside the workloads")
     ap.add_argument("--secondary-steps", type=int, default=30, help="time steps per timed batch of a secondary workload")
     ap.add_argument("--secondary-only", action="store_true", help="skip the headline (profiling passes)")
     return ap.parse_args(argv)
@@ -787,6 +843,13 @@ def main(argv=None):
                      "note": "same kernel family, collision in the reference's operation order (bitwise equal to the CPU oracle)"}
         lib.set_tuning(b"bgk_fast", int(tune.get("bgk_fast", "-1")))
 
+    power = None
+    if world == 1 and rank == 0 and not a.no_power:
+        def _some():
+            box.advance(20 * D)
+            torch.cuda.synchronize()
+        power = power_probe(_some)
+
     out = None
     if rank == 0:
         lups = R * C * world * a.steps / dt
@@ -846,6 +909,8 @@ def main(argv=None):
         elif valu is not None:
             roof["valu_issue_frac"] = valu
             roof["valu_issue_frac_source"] = "committed SQ pass (profiles/), not this run"
+        if power:
+            roof["power"] = power
         if live:
             roof["pmc"] = live
             roof["minimum_bytes_per_launch"] = R * C * BYTES_PER_LUP     # one read + one write of the lattice
