@@ -77,6 +77,8 @@ static int launch_cg_collide(bool from_post, double* pn_r, double* pn_b, const d
   return LBM_OK;
 }
 
+static thread_local int g_last_inner_form = -1;  // lbm_cg_last_inner_form
+
 template <int TR, int TC, int WAVES>
 static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, const double* in_b,
                              const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
@@ -101,6 +103,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   rc.ic1 = (g.C - 3) / TC;  // last tile column with c_base + TC + 1 <= C - 2
   if (rc.ic1 > tiles_c) rc.ic1 = tiles_c;
   const bool split = tuning("cg_split", 1) != 0 && rc.ir1 - rc.ir0 >= 1 && rc.ic1 - rc.ic0 >= 1;
+  g_last_inner_form = 0;
   if (!split) {
     if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
     else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
@@ -144,6 +147,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     if (rpc > rb - ra) rpc = rb - ra;
     const int chunks = (rb - ra + rpc - 1) / rpc, nb = strips * chunks, grid = (nb + 7) / 8 * 8;
     const int xo = tuning("cg_walk_xcd", 1);
+    g_last_inner_form = sw4;
 #define LBM_CG_WALK(WTR, WWC)                                                                                          \
     if (psi) LBM_KLAUNCH((k_cg_walk<WTR, WWC, true>), dim3(grid), dim3(WTR * WWC * 64), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo); \
     else LBM_KLAUNCH((k_cg_walk<WTR, WWC, false>), dim3(grid), dim3(WTR * WWC * 64), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo);
@@ -156,6 +160,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     }
 #undef LBM_CG_WALK
   } else
+#ifdef LBM_EXPERIMENTS
   // 31 / 32: k_cg_strip5 -- private windows, 2 / 4 adjacent strips per workgroup, a barrier every "cg_sync" rows (0: none)
   if ((sw4 == 31 || sw4 == 32) && rc.ic0 * TC >= 8) {
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
@@ -170,6 +175,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     }
     if (rpc > rb - ra) rpc = rb - ra;
     const int chunks = (rb - ra + rpc - 1) / rpc, sync = tuning("cg_sync", 8);
+    g_last_inner_form = sw4;
 #define LBM_CG_S5(WV)                                                                                              \
     if (psi) LBM_KLAUNCH((k_cg_strip5<WV, true>), dim3(groups * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, groups, sync); \
     else LBM_KLAUNCH((k_cg_strip5<WV, false>), dim3(groups * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, groups, sync);
@@ -191,31 +197,23 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     }
     if (rpc > rb - ra) rpc = rb - ra;
     const int chunks = (rb - ra + rpc - 1) / rpc;
+    g_last_inner_form = sw4;
 #define LBM_CG_S4(WV)                                                                                              \
     if (psi) LBM_KLAUNCH((k_cg_strip4<WV, true>), dim3(bstrips * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, bstrips, win0); \
     else LBM_KLAUNCH((k_cg_strip4<WV, false>), dim3(bstrips * chunks), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, bstrips, win0);
     if (sw4 == 21) { LBM_CG_S4(4) } else { LBM_CG_S4(8) }
 #undef LBM_CG_S4
   } else
-#ifdef LBM_EXPERIMENTS
-  if (const int sw = (sw4 == 21 || sw4 == 22) ? 0 : sw4) {  // the inner rectangle through a register-ring strip kernel
-#else
-  if (const int sw = (sw4 == 11 || sw4 == 12) ? sw4 : 0) {  // 11 / 12: k_cg_strip3 (private 64-column windows, colour sums in LDS)
-#endif
+  if (const int sw = (sw4 >= 21) ? 0 : sw4) {  // the inner rectangle through a register-ring strip kernel
     // 1, 2, 4: k_cg_strip2 (one wave per SIMD) with that many waves per workgroup; 11, 12: k_cg_strip3 (colour sums
     // of the ring rows in LDS, two waves per SIMD) with 1 / 2 waves per workgroup
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
     const int strips = (cb - ca + CG_SW2 - 1) / CG_SW2;
-#ifdef LBM_EXPERIMENTS
     const void* kfn = sw == 2 ? (psi ? (const void*)k_cg_strip2<2, true> : (const void*)k_cg_strip2<2, false>)
                     : sw == 1 ? (psi ? (const void*)k_cg_strip2<1, true> : (const void*)k_cg_strip2<1, false>)
                     : sw == 11 ? (psi ? (const void*)k_cg_strip3<1, true> : (const void*)k_cg_strip3<1, false>)
                     : sw == 12 ? (psi ? (const void*)k_cg_strip3<2, true> : (const void*)k_cg_strip3<2, false>)
                                : (psi ? (const void*)k_cg_strip2<4, true> : (const void*)k_cg_strip2<4, false>);
-#else
-    const void* kfn = sw == 11 ? (psi ? (const void*)k_cg_strip3<1, true> : (const void*)k_cg_strip3<1, false>)
-                               : (psi ? (const void*)k_cg_strip3<2, true> : (const void*)k_cg_strip3<2, false>);
-#endif
     const int wv = sw == 2 || sw == 12 ? 2 : (sw == 1 || sw == 11 ? 1 : 4);
     // rows per wave: at 16.8 M nodes the launch is only 1-3 rounds of resident waves deep -- a chunk height
     // that leaves the last round nearly empty costs up to a whole round; fit it to the resident wave slots
@@ -226,11 +224,10 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     }
     if (rpc > rb - ra) rpc = rb - ra;
     const int chunks = (rb - ra + rpc - 1) / rpc, n_waves = strips * chunks;
-#ifdef LBM_EXPERIMENTS
+    g_last_inner_form = sw;
 #define LBM_CG_S2(KERNEL, WV)                                                                                      \
     if (psi) LBM_KLAUNCH((KERNEL<WV, true>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves); \
     else LBM_KLAUNCH((KERNEL<WV, false>), dim3((n_waves + WV - 1) / WV), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves);
-#endif
     const int xo = tuning("cg_strip_xcd", 0);  // strip3: XCD k takes the k-th contiguous eighth of the strip sequence (measured: no effect)
 #define LBM_CG_S3(WV)                                                                                              \
     {                                                                                                              \
@@ -238,16 +235,13 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
       if (psi) LBM_KLAUNCH((k_cg_strip3<WV, true>), dim3(grid3), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves, xo); \
       else LBM_KLAUNCH((k_cg_strip3<WV, false>), dim3(grid3), dim3(64 * WV), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, n_waves, xo); \
     }
-#ifdef LBM_EXPERIMENTS
     if (sw == 2) { LBM_CG_S2(k_cg_strip2, 2) } else if (sw == 1) { LBM_CG_S2(k_cg_strip2, 1) }
     else if (sw == 11) LBM_CG_S3(1) else if (sw == 12) LBM_CG_S3(2)
     else { LBM_CG_S2(k_cg_strip2, 4) }
 #undef LBM_CG_S2
-#else
-    if (sw == 11) LBM_CG_S3(1) else LBM_CG_S3(2)
-#endif
 #undef LBM_CG_S3
   } else
+#endif  // LBM_EXPERIMENTS (strip kernels)
   if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
   else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 1>), dim3(inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc);
   LBM_CHECK_LAUNCH();
@@ -594,6 +588,7 @@ static int cg_solver_step2(lbm_cg_solver* sv) {
 #endif  // LBM_EXPERIMENTS
 
 long long lbm_cg_solver_pair_launches(const lbm_cg_solver* sv) { return sv ? sv->pair_launches : -1; }
+int lbm_cg_last_inner_form(void) { return lbm::g_last_inner_form; }
 
 int lbm_cg_solver_step(lbm_cg_solver* sv, int n_steps) {
   LBM_REQUIRE(sv && n_steps >= 0, "lbm_cg_solver_step: bad argument");

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
                                            row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x, (int)gridDim.x);
 }
 
-#ifdef LBM_EXPERIMENTS  // the launch forms below were measured and not kept (DESIGN.md "experiments"): make EXPERIMENTS=1
+#ifdef LBM_EXPERIMENTS  // the launch forms below (merged dispatch, strip kernels 1 - 4) were measured and not kept: make EXPERIMENTS=1
 // frame tiles and inner tiles in ONE dispatch: workgroups [0, n_frame) run the frame instantiation (general boundary
 // gather), the rest the inner one (plain offsets).  The two-launch form either runs the frame behind the inner launch
 // (63 us) or beside it on a helper stream, whose event fork / join costs as much as it hides (profiles/r02_ring_dissect.txt).
@@ -699,11 +699,6 @@ __global__ __launch_bounds__(64 * WAVES, 1) void k_cg_strip2(
 }
 
 
-#endif  // LBM_EXPERIMENTS
-#ifndef LBM_EXPERIMENTS
-constexpr int CG_SW2 = 56;  // output columns per wave of the strip kernels with private windows
-#endif
-
 // ---- third generation: two waves per SIMD -----------------------------------------------------------------
 // k_cg_strip2 needs ~390 registers (one wave per SIMD: every dependent chain of the collision is exposed).
 // Here the colour-summed populations of the 3 ring rows wait in wave-private LDS instead (13.8 KB per wave;
@@ -981,6 +976,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_cg_strip4(
   }
 }
 
+#endif  // LBM_EXPERIMENTS (strip kernels, generations 1 - 4)
+
 __device__ __forceinline__ void cg_reduce_row(const double (&fr)[Q], double (&ft)[Q], const CgFast& cf, double (&n6)[6],
                                               double& psi, double& qx, double& qy) {
 #pragma clang fp contract(on)
@@ -1001,6 +998,7 @@ __device__ __forceinline__ void cg_reduce_row(const double (&fr)[Q], double (&ft
   n6[0] = rr; n6[1] = rb; n6[2] = ux; n6[3] = uy; n6[4] = irt; n6[5] = psi;
 }
 
+#ifdef LBM_EXPERIMENTS  // 14.0-14.3 k against the tile kernel's 15.3 k
 // ---- fifth form: k_cg_strip3's private windows, FOUR adjacent strips per workgroup kept loosely together -------------------
 // The calibration of round 3 says neighbouring strips share a 128-byte line only inside one workgroup at about the same
 // time; k_cg_strip4 buys that with a shared ring and a barrier per row and loses more to the lockstep than it gains.  Here
@@ -1106,6 +1104,8 @@ __global__ __launch_bounds__(64 * W, 2) void k_cg_strip5(
     for (int q = 0; q < Q; ++q) s_ft[i & 1][q][lane] = ft[q];
   }
 }
+
+#endif  // LBM_EXPERIMENTS (fifth form)
 
 // ---- sixth form: a workgroup of TR x WC waves walks down a strip, TR rows a step ---------------------------------------
 // Between the tile kernel (16 waves per CU, moves its actual traffic at 6.4-6.7 TB/s, but reduces 22 x 36 nodes for 16 x 32

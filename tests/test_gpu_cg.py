@@ -284,9 +284,9 @@ def test_cg_fused_two_slabs_equal_single_block(lib, oracle):
 
 @pytest.mark.parametrize("R,C", [(64, 32), (256, 200), (130, 61), (200, 544), (130, 1040)])
 def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
-    """The two one-launch kernels -- LDS tile (default) and column-strip sliding window
-    (tuning cg_strip = 1 / 2 / 4), the tile kernel with and without its inner / frame split (cg_split) -- share the per-node arithmetic (FMA per source expression): identical
-    bits after 7 steps, including partial strips, partial chunks and the wall / copy edges."""
+    """The one-launch kernels -- LDS tile (default) with and without its inner / frame split (cg_split), the walking block
+    (cg_strip2 = 41 / 42) and, in an EXPERIMENTS build, the strip kernels -- share the per-node arithmetic (FMA per source
+    expression): identical bits after 7 steps, including partial strips, partial chunks and the wall / copy edges."""
     import ctypes as ct
     from gpu_util import dev, upload_soa
     from pylbm import _ptr
@@ -307,12 +307,13 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         # the general boundary gather
         # strip >= 10: the inner rectangle through the register-ring strip kernel (cg_strip2 = strip - 10 waves
         # per workgroup, cg_rows2 rows per chunk), the frame through the tile kernel
-        cases = [(0, 64), (0, 0), (21, 40), (22, 9),                  # tile kernel split / unsplit; 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
-                 (31, 40), (31, 7), (32, 9), (32, 64),                # 31 / 32: the lockstep block kernel (cg_strip2 = 21 / 22)
-                 (41, 40), (42, 9), (42, 64), (42, 33),               # 41 / 42: adjacent strips kept loosely together (cg_strip2 = 31 / 32)
-                 (51, 40), (51, 16), (52, 9), (52, 64), (52, 24)]     # 51 / 52: the walking tile (cg_strip2 = 41 / 42)
-        if lib.raw.lbm_build_has_experiments():                       # the first two strip generations (make EXPERIMENTS=1)
-            cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33)]
+        cases = [(0, 64), (0, 0),                                      # tile kernel split / unsplit
+                 (51, 40), (51, 16), (52, 9), (52, 64), (52, 24)]      # 51 / 52: the walking block (cg_strip2 = 41 / 42: 4 x 1, 6 x 1 waves)
+        if lib.raw.lbm_build_has_experiments():                       # the strip kernels, generations 1 - 5 (make EXPERIMENTS=1)
+            cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33),
+                      (21, 40), (22, 9),                               # 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
+                      (31, 40), (31, 7), (32, 9), (32, 64),            # 31 / 32: the lockstep block kernel (cg_strip2 = 21 / 22)
+                      (41, 40), (42, 9), (42, 64), (42, 33)]           # 41 / 42: adjacent strips kept loosely together (cg_strip2 = 31 / 32)
         for strip, rows in cases:
             lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
             lib.set_tuning(b"cg_strip2", strip - 10 if strip >= 10 else 0)
@@ -326,6 +327,9 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                 a, b = b, a
             torch.cuda.synchronize()
             res[(strip, rows)] = a
+            if strip >= 50 or strip == 0:   # the opt-in form really ran where the lattice has an inner rectangle
+                want = strip - 10 if (strip and rows and C >= 100) else 0
+                assert lib.raw.lbm_cg_last_inner_form() == want, (strip, rows, lib.raw.lbm_cg_last_inner_form())
     finally:
         lib.set_tuning(b"cg_strip", -1)
         lib.set_tuning(b"cg_strip2", -1)
