@@ -79,3 +79,28 @@ def test_config4_fullsize_two_phase_step_vs_oracle(lib, oracle, mode):
                 assert relerr(got[k], want[k]) < 1e-11, (k, relerr(got[k], want[k]))
     finally:
         lib.set_tuning(b"cg_fused", -1)
+
+
+@pytest.mark.parametrize("form", [41, 42])
+def test_config4_fullsize_walking_block_equals_tile_kernel(lib, oracle, form):
+    """8192 x 2048, 4 iterations through lbm_cg_solver_step: the opt-in walking block (cg_strip2 = 41 / 42: 22 chunks of
+    34 strips, XCD-contiguous order, 32-bit plane offsets) leaves the SAME BITS as the default tile kernel -- populations
+    of both colours and every observable field -- and it is the form that ran."""
+    R, C, n = 8192, 2048, 4
+    po = pyoracle.cg_params(R, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    got = {}
+    try:
+        for f in (0, form):
+            lib.set_tuning(b"cg_strip2", f)
+            sv = pylbm.CgSolver(lib, R, C, pg)
+            sv.set_state(s0["f_r"], s0["f_b"], s0["rho_r"], s0["rho_b"], s0["u"])
+            sv.step(n)
+            got[f] = sv.get_state()
+            assert lib.raw.lbm_cg_last_inner_form() == f
+            sv.close()
+    finally:
+        lib.set_tuning(b"cg_strip2", -1)
+    for k in got[0]:
+        assert bits_equal(got[form][k], got[0][k]), (k, ulp_diff(got[form][k], got[0][k]))
