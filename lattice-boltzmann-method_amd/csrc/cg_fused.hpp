@@ -106,35 +106,39 @@ __device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restr
   return n;
 }
 
+// {a0[j], a1[j]}: the taps of the stencil, in constant memory.  The loops below stay rolled (unrolled, the scheduler hoists
+// all LDS reads of a stencil to the top: ~100 extra live VGPRs) and index the taps with their -- wave-uniform -- counter:
+// from here that is one s_load_dwordx4 per step; from a constexpr array it was a chain of 15 v_cndmask per step, more
+// VALU instructions than the 8 f64 operations they fed (found on k_cg_walk's ISA, round 3).
+static __constant__ double CG_STENCIL_TAPS[5][2] = {
+    {2 * (1.0 / 5040.0) * 1, (1.0 / 5040.0) * 32},  {2 * (1.0 / 5040.0) * 32, (1.0 / 5040.0) * 448},
+    {2 * (1.0 / 5040.0) * 84, (1.0 / 5040.0) * 960}, {2 * (1.0 / 5040.0) * 32, (1.0 / 5040.0) * 448},
+    {2 * (1.0 / 5040.0) * 1, (1.0 / 5040.0) * 32}};
 // 5x5 isotropic derivative (differential.hpp:9-16) with the antisymmetric taps paired.
 // d/d(row): sum_j [ 2 a0_j (P[4][j] - P[0][j]) + a1_j (P[3][j] - P[1][j]) ]; d/d(col) transposed.
 template <int LDC>
 __device__ __forceinline__ double cg_ddrow(const double (*s)[LDC], int tr, int tc) {
 #pragma clang fp contract(on)
-  constexpr double k = 1.0 / 5040.0;
-  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
   double acc = 0.0;
   // NOT unrolled: unrolled, the scheduler hoists the 20 LDS reads of each of the four stencils to the
   // top of the collision (~100 extra live VGPRs: 196 instead of 96 for stencil + collision)
 #pragma unroll 1
   for (int j = 0; j < 5; ++j) {
-    acc += a0[j] * (s[tr + 4][tc + j] - s[tr][tc + j]);
-    acc += a1[j] * (s[tr + 3][tc + j] - s[tr + 1][tc + j]);
+    const double a0 = CG_STENCIL_TAPS[j][0], a1 = CG_STENCIL_TAPS[j][1];
+    acc += a0 * (s[tr + 4][tc + j] - s[tr][tc + j]);
+    acc += a1 * (s[tr + 3][tc + j] - s[tr + 1][tc + j]);
   }
   return acc;
 }
 template <int LDC>
 __device__ __forceinline__ double cg_ddcol(const double (*s)[LDC], int tr, int tc) {
 #pragma clang fp contract(on)
-  constexpr double k = 1.0 / 5040.0;
-  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
   double acc = 0.0;
 #pragma unroll 1
   for (int i = 0; i < 5; ++i) {
-    acc += a0[i] * (s[tr + i][tc + 4] - s[tr + i][tc]);
-    acc += a1[i] * (s[tr + i][tc + 3] - s[tr + i][tc + 1]);
+    const double a0 = CG_STENCIL_TAPS[i][0], a1 = CG_STENCIL_TAPS[i][1];
+    acc += a0 * (s[tr + i][tc + 4] - s[tr + i][tc]);
+    acc += a1 * (s[tr + i][tc + 3] - s[tr + i][tc + 1]);
   }
   return acc;
 }
@@ -1255,26 +1259,28 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
         rs[i] = b + m + i;
         rs[i] -= rs[i] >= NR ? NR : 0;
       }
-      constexpr double kk = 1.0 / 5040.0;
-      constexpr double a0[5] = {2 * kk * 1, 2 * kk * 32, 2 * kk * 84, 2 * kk * 32, 2 * kk * 1};
-      constexpr double a1[5] = {kk * 32, kk * 448, kk * 960, kk * 448, kk * 32};
       const int l0 = l - 2;  // columns c - 2 .. c + 2 sit at [l0 .. l0 + 4]
-      double gx = 0.0, dxqx = 0.0;
+      // rolled (unrolled, the 80 LDS reads are hoisted on top of each other and spill -- scheduling barriers do not stop
+      // it), with the coefficients of step j read from constant memory by the scalar unit: indexing the constexpr arrays
+      // with the loop counter cost 15 v_cndmask per step for 8 f64 operations.  Same operations, same order, same values
+      // as cg_ddrow / cg_ddcol.
+      double gx = 0.0, dxqx = 0.0, gy = 0.0, dyqy = 0.0;
 #pragma unroll 1
       for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-        gx += a0[j] * (s_psi[rs[4]][l0 + j] - s_psi[rs[0]][l0 + j]);
-        gx += a1[j] * (s_psi[rs[3]][l0 + j] - s_psi[rs[1]][l0 + j]);
-        dxqx += a0[j] * (s_qx[rs[4]][l0 + j] - s_qx[rs[0]][l0 + j]);
-        dxqx += a1[j] * (s_qx[rs[3]][l0 + j] - s_qx[rs[1]][l0 + j]);
+        const double c0 = CG_STENCIL_TAPS[j][0], c1 = CG_STENCIL_TAPS[j][1];
+        gx += c0 * (s_psi[rs[4]][l0 + j] - s_psi[rs[0]][l0 + j]);
+        gx += c1 * (s_psi[rs[3]][l0 + j] - s_psi[rs[1]][l0 + j]);
+        dxqx += c0 * (s_qx[rs[4]][l0 + j] - s_qx[rs[0]][l0 + j]);
+        dxqx += c1 * (s_qx[rs[3]][l0 + j] - s_qx[rs[1]][l0 + j]);
       }
-      double gy = 0.0, dyqy = 0.0;
       int sl = rs[0];
 #pragma unroll 1
       for (int i = 0; i < 5; ++i) {  // == cg_ddcol
-        gy += a0[i] * (s_psi[sl][l0 + 4] - s_psi[sl][l0]);
-        gy += a1[i] * (s_psi[sl][l0 + 3] - s_psi[sl][l0 + 1]);
-        dyqy += a0[i] * (s_qy[sl][l0 + 4] - s_qy[sl][l0]);
-        dyqy += a1[i] * (s_qy[sl][l0 + 3] - s_qy[sl][l0 + 1]);
+        const double c0 = CG_STENCIL_TAPS[i][0], c1 = CG_STENCIL_TAPS[i][1];
+        gy += c0 * (s_psi[sl][l0 + 4] - s_psi[sl][l0]);
+        gy += c1 * (s_psi[sl][l0 + 3] - s_psi[sl][l0 + 1]);
+        dyqy += c0 * (s_qy[sl][l0 + 4] - s_qy[sl][l0]);
+        dyqy += c1 * (s_qy[sl][l0 + 3] - s_qy[sl][l0 + 1]);
         sl = sl + 1 >= NR ? 0 : sl + 1;
       }
       CgNode me;
