@@ -137,12 +137,9 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     const int wtr = shapes[sw4 - 41][0], wc = shapes[sw4 - 41][1], outc = 64 * wc - 4;
     const int strips = (cb - ca + outc - 1) / outc;
     int rpc = tuning("cg_rows2", 0);
-    if (rpc <= 0) {  // every workgroup resident at once (12 waves per CU), no chunk shorter than 16 steps
-      const int slots = 256 * 12 / (wtr * wc);
-      int chunks = slots / strips < 1 ? 1 : slots / strips;
-      rpc = (rb - ra + chunks - 1) / chunks;
-      if (rpc < 16 * wtr) rpc = 16 * wtr;
-    }
+    // chunks of 128 rows: several rounds of workgroups, dispatched as slots free up.  One round of long chunks (every
+    // workgroup resident at once) is 6-8 % slower on six boxes of nine: a static partition ends with its slowest workgroup
+    if (rpc <= 0) rpc = 128;
     rpc = (rpc + wtr - 1) / wtr * wtr;
     if (rpc > rb - ra) rpc = rb - ra;
     const int chunks = (rb - ra + rpc - 1) / rpc, nb = strips * chunks, grid = (nb + 7) / 8 * 8;
