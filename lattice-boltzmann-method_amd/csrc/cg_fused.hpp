@@ -1121,8 +1121,10 @@ __global__ __launch_bounds__(64 * W, 2) void k_cg_strip5(
 // nodes: each (plane, row) is read once per strip.  The loads of step k + 1 are issued right after the barrier and arrive
 // behind the collision of step k (3 waves per SIMD: 168 VGPRs hold both).  Per-node arithmetic = the tile kernel's:
 // identical bits.
-// Addresses are a workgroup-uniform 64-bit base (scalar unit, every step) plus ONE 32-bit byte offset per thread; the
-// asm barriers keep the compiler from hoisting 36 + 18 per-thread plane addresses out of the walk loop (it spills them).
+// Addresses: one uniform 64-bit base per lattice and chunk + (32-bit scalar plane offset + this thread's 32-bit byte
+// offset), the saddr form.  The empty asm statements make the step's row and the lane index opaque per step: left alone,
+// the compiler hoists 36 + 18 per-thread plane addresses (and every LDS address) out of the walk loop and spills them,
+// and a spill reload waits behind the prefetched loads (vmcnt counts in order).
 __device__ __forceinline__ double cg_ld(const double* __restrict__ base, unsigned voff) {
   return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + voff);
 }
