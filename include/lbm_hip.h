@@ -314,7 +314,7 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
                       int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* s_nu,
                       lbm_stream_t s);
 /* which kernel the calling thread's last lbm_cg_step_fused launched for the INNER rectangle of the lattice: 0 the LDS tile
- * kernel (default), 41..45 the walking block (tuning "cg_strip2"), other values the strip kernels of an
+ * kernel (default), 41..47 the walking block (tuning "cg_strip2"), other values the strip kernels of an
  * EXPERIMENTS build; -1 before the first call.  An opt-in form the geometry does not admit falls back to the tile kernel --
  * this says so (tests/test_gpu_cg.py asserts on it). */
 int lbm_cg_last_inner_form(void);

@@ -130,10 +130,10 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     LBM_CHECK_LAUNCH();
   }
   const int sw4 = tuning("cg_strip2", 0);
-  // 41 .. 45: k_cg_walk -- a workgroup of TR x WC waves walking down a strip of 64 WC - 4 columns, TR rows a step
-  if (sw4 >= 41 && sw4 <= 45 && rc.ic0 * TC >= 4 && 9.0 * (double)g.plane * 8.0 < 4.0e9) {  // 32-bit plane offsets
+  // 41 .. 47: k_cg_walk -- a workgroup of TR x WC waves walking down a strip of 64 WC - 4 columns, TR rows a step
+  if (sw4 >= 41 && sw4 <= 47 && rc.ic0 * TC >= 4 && 9.0 * (double)g.plane * 8.0 < 4.0e9) {  // 32-bit plane offsets
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;
-    static const int shapes[5][2] = {{4, 1}, {6, 1}, {2, 2}, {3, 2}, {2, 3}};
+    static const int shapes[7][2] = {{4, 1}, {6, 1}, {2, 2}, {3, 2}, {2, 3}, {2, 1}, {3, 1}};
     const int wtr = shapes[sw4 - 41][0], wc = shapes[sw4 - 41][1], outc = 64 * wc - 4;
     const int strips = (cb - ca + outc - 1) / outc;
     int rpc = tuning("cg_rows2", 0);
@@ -153,7 +153,9 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
       case 42: LBM_CG_WALK(6, 1) break;
       case 43: LBM_CG_WALK(2, 2) break;
       case 44: LBM_CG_WALK(3, 2) break;
-      default: LBM_CG_WALK(2, 3) break;
+      case 45: LBM_CG_WALK(2, 3) break;
+      case 46: LBM_CG_WALK(2, 1) break;
+      default: LBM_CG_WALK(3, 1) break;
     }
 #undef LBM_CG_WALK
   } else

@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
   static_assert(TR >= 2, "two rows of threads park their node for a step");
   constexpr int LW = 64 * WC, OUTC = LW - 4, NR = 2 * TR + 4, NP = 2 * LW, KW = (4 + TR - 1) / TR;
   __shared__ double s_psi[NR][LW], s_qx[NR][LW], s_qy[NR][LW];
-  __shared__ double s_park[2][15][NP];  // [step parity][9 colour sums, rho_r, rho_b, u_x, u_y, 1 / rho, psi][thread]
+  __shared__ double s_park[15][NP];  // [9 colour sums, rho_r, rho_b, u_x, u_y, 1 / rho, psi][thread]: each thread's own column
   int blk = blockIdx.x;
   // XCD k takes the k-th contiguous eighth of the (chunk-major, strip-minor) sequence: the column neighbours of a
   // workgroup -- which read the same 128-byte lines at the window edges -- walk beside it behind the same L2
@@ -1233,28 +1233,30 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
       s_qx[sl][l] = qx;
       s_qy[sl][l] = qy;
     }
-    if (parks) {
-      double(*pk)[NP] = s_park[(k + 1) & 1];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) pk[q][pl] = ft[q];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) pk[9 + q][pl] = n6[q];
-    }
     if (!stored) flush(Rk - TR, l);
     stored = true;
+    // a parking thread swaps the node it has just reduced for the one it parked a step ago (its own column of s_park: read,
+    // then write -- one buffer); here, behind the flush, neither the prefetched rows nor the deferred results are live
+    if (parks) {
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const double t = s_park[q][pl];
+        s_park[q][pl] = ft[q];
+        ft[q] = t;
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double t = s_park[9 + q][pl];
+        s_park[9 + q][pl] = n6[q];
+        n6[q] = t;
+      }
+    }
     __syncthreads();  // the fields of rows Rk - 2 .. Rk + TR + 1 are in the ring
     // (no second barrier: the next step's rows take the slots of rows Rk - TR - 2 .. Rk - 3, which nobody reads any more,
     // and no wave gets two steps ahead -- it would have to pass the next barrier first)
     if (k + 1 < n_steps) issue(k + 1);
     const int m = parks ? tr - (TR - 2) : tr + 2;  // this thread collides row Rk + m
     if (k >= 0 && lane_out && Rk + m < R1) {
-      if (parks) {
-        const double(*pk)[NP] = s_park[k & 1];
-#pragma unroll
-        for (int q = 0; q < Q; ++q) ft[q] = pk[q][pl];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) n6[q] = pk[9 + q][pl];
-      }
       int rs[5];
 #pragma unroll
       for (int i = 0; i < 5; ++i) {

@@ -308,7 +308,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         # strip >= 10: the inner rectangle through the register-ring strip kernel (cg_strip2 = strip - 10 waves
         # per workgroup, cg_rows2 rows per chunk), the frame through the tile kernel
         cases = [(0, 64), (0, 0),                                      # tile kernel split / unsplit
-                 (51, 40), (51, 16), (52, 9), (52, 64), (52, 24)]      # 51 / 52: the walking block (cg_strip2 = 41 / 42: 4 x 1, 6 x 1 waves)
+                 (51, 40), (51, 16), (52, 9), (52, 64), (52, 24),      # 51 / 52: the walking block (cg_strip2 = 41 / 42: 4 x 1, 6 x 1 waves)
+                 (53, 40), (54, 33), (55, 64), (56, 40), (56, 7), (57, 40), (57, 9)]  # ... 2 x 2, 3 x 2, 2 x 3, 2 x 1, 3 x 1 waves
         if lib.raw.lbm_build_has_experiments():                       # the strip kernels, generations 1 - 5 (make EXPERIMENTS=1)
             cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33),
                       (21, 40), (22, 9),                               # 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
