@@ -145,6 +145,10 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     const int chunks = (rb - ra + rpc - 1) / rpc, nb = strips * chunks, grid = (nb + 7) / 8 * 8;
     const int xo = tuning("cg_walk_xcd", 1);
     g_last_inner_form = sw4;
+    if (sw4 == 41 && tuning("cg_walk_pf", 1) == 0) {  // the 4 x 1 block without prefetch, 4 waves per SIMD
+      if (psi) LBM_KLAUNCH((k_cg_walk<4, 1, true, false>), dim3(grid), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo);
+      else LBM_KLAUNCH((k_cg_walk<4, 1, false, false>), dim3(grid), dim3(256), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo);
+    } else
 #define LBM_CG_WALK(WTR, WWC)                                                                                          \
     if (psi) LBM_KLAUNCH((k_cg_walk<WTR, WWC, true>), dim3(grid), dim3(WTR * WWC * 64), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo); \
     else LBM_KLAUNCH((k_cg_walk<WTR, WWC, false>), dim3(grid), dim3(WTR * WWC * 64), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, rb, ca, cb, rpc, strips, nb, xo);

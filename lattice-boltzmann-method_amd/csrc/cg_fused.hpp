@@ -1135,8 +1135,11 @@ __device__ __forceinline__ void cg_st(double v, double* __restrict__ base, unsig
   *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + voff) = v;
 }
 
-template <int TR, int WC, bool WITH_FIELDS>
-__global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
+// PF (default): the next step's rows prefetched behind the collision, results stored a step late, 3 waves per SIMD.
+// !PF: rows loaded at the head of their step and results stored at its end (the wait for the rows then covers the
+// stores issued before them -- both in flight together), nothing carried over the collision: 4 waves per SIMD.
+template <int TR, int WC, bool WITH_FIELDS, bool PF = true>
+__global__ __launch_bounds__(TR* WC * 64, PF ? 3 : 4) void k_cg_walk(
     double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
     const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
     double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
@@ -1208,8 +1211,9 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
       cg_st(of[5], snu_out + oo, v_out);
     }
   };
-  issue(-KW);
+  if (PF) issue(-KW);
   for (int k = -KW; k < n_steps; ++k) {  // k < 0: rows R0 - 2 .. R0 + 1 only, nothing collided
+    if (!PF) issue(k);
     int Rk = R0 + k * TR;
     asm volatile("" : "+s"(Rk));
     CgFast cfl = cf;
@@ -1254,7 +1258,7 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
     __syncthreads();  // the fields of rows Rk - 2 .. Rk + TR + 1 are in the ring
     // (no second barrier: the next step's rows take the slots of rows Rk - TR - 2 .. Rk - 3, which nobody reads any more,
     // and no wave gets two steps ahead -- it would have to pass the next barrier first)
-    if (k + 1 < n_steps) issue(k + 1);
+    if (PF && k + 1 < n_steps) issue(k + 1);
     const int m = parks ? tr - (TR - 2) : tr + 2;  // this thread collides row Rk + m
     if (k >= 0 && lane_out && Rk + m < R1) {
       int rs[5];
@@ -1297,6 +1301,10 @@ __global__ __launch_bounds__(TR* WC * 64, 3) void k_cg_walk(
         of[0] = me.rr; of[1] = me.rb; of[2] = me.ux; of[3] = me.uy; of[4] = me.psi; of[5] = s_nu;
       }
       stored = false;
+      if (!PF) {
+        flush(Rk, l);
+        stored = true;
+      }
     }
   }
   if (!stored) flush(R0 + (n_steps - 1) * TR, l_);

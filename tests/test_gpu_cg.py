@@ -309,7 +309,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         # per workgroup, cg_rows2 rows per chunk), the frame through the tile kernel
         cases = [(0, 64), (0, 0),                                      # tile kernel split / unsplit
                  (51, 40), (51, 16), (52, 9), (52, 64), (52, 24),      # 51 / 52: the walking block (cg_strip2 = 41 / 42: 4 x 1, 6 x 1 waves)
-                 (53, 40), (54, 33), (55, 64), (56, 40), (56, 7), (57, 40), (57, 9)]  # ... 2 x 2, 3 x 2, 2 x 3, 2 x 1, 3 x 1 waves
+                 (53, 40), (54, 33), (55, 64), (56, 40), (56, 7), (57, 40), (57, 9),  # ... 2 x 2, 3 x 2, 2 x 3, 2 x 1, 3 x 1 waves
+                 (61, 40), (61, 16)]                                   # 61: 4 x 1 without prefetch (cg_walk_pf = 0), 4 waves per SIMD
         if lib.raw.lbm_build_has_experiments():                       # the strip kernels, generations 1 - 5 (make EXPERIMENTS=1)
             cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33),
                       (21, 40), (22, 9),                               # 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
@@ -317,7 +318,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                       (41, 40), (42, 9), (42, 64), (42, 33)]           # 41 / 42: adjacent strips kept loosely together (cg_strip2 = 31 / 32)
         for strip, rows in cases:
             lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
-            lib.set_tuning(b"cg_strip2", strip - 10 if strip >= 10 else 0)
+            lib.set_tuning(b"cg_strip2", 41 if strip == 61 else (strip - 10 if strip >= 10 else 0))
+            lib.set_tuning(b"cg_walk_pf", 0 if strip == 61 else -1)
             lib.set_tuning(b"cg_rows2", rows if rows else 64)
             lib.set_tuning(b"cg_rows", rows if rows else 64)
             lib.set_tuning(b"cg_split", 1 if rows else 0)
@@ -329,11 +331,12 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
             torch.cuda.synchronize()
             res[(strip, rows)] = a
             if strip >= 50 or strip == 0:   # the opt-in form really ran where the lattice has an inner rectangle
-                want = strip - 10 if (strip and rows and C >= 100) else 0
+                want = (41 if strip == 61 else strip - 10) if (strip and rows and C >= 100) else 0
                 assert lib.raw.lbm_cg_last_inner_form() == want, (strip, rows, lib.raw.lbm_cg_last_inner_form())
     finally:
         lib.set_tuning(b"cg_strip", -1)
         lib.set_tuning(b"cg_strip2", -1)
+        lib.set_tuning(b"cg_walk_pf", -1)
         lib.set_tuning(b"cg_rows2", -1)
         lib.set_tuning(b"cg_rows", -1)
         lib.set_tuning(b"cg_split", -1)
