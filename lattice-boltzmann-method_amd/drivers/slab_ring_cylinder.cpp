@@ -20,6 +20,7 @@
 //                      else, and all slabs finish a block together); --uniform 1: N equal slabs (the cylinder then
 //                      straddles a seam of the BASELINE layout); --slab-rows r0,r1,...: heights by hand;
 //                      --costs far_us_per_row,owner_us,owner_us_per_row: the planner's cost model instead of its table
+//                      --form reference|reassociated: the collision's operation order (default: the library's, i.e. bitwise to the oracle)
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_cylinder --id-file /tmp/x ...
 //
 // tau = 0.55 (parameters.toml), u_in = 0.04 (SURVEY 8d allows a smaller u for the benchmark), markers
@@ -37,6 +38,7 @@ namespace {
 struct Args {
   int rows = 2048, cols = 4096, steps = 50, warmup = 5, edge_rows = 32, check = 0, diameter = 300;
   int depth = 5, centre_row = -1, emulate = 0, uniform = 0;
+  int form = LBM_FORM_DEFAULT;  // --form reference|reassociated: the collision's operation order (lbm_bgk_params.form)
   std::string id_file;
   std::string slab_rows;  // comma-separated slab heights (default: planned by the library)
   std::string costs;      // far_us_per_row,owner_us,owner_us_per_row for the planner
@@ -132,6 +134,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   prm.omega = 1.0 / kTau;
   prm.incompressible = 0;
   prm.delta_form = 1;  // :123-125
+  prm.form = a.form;
   lbm_bc bc = global_bc();
 
   std::vector<double> mx, my;
@@ -273,6 +276,7 @@ int run_emulated(const Args& a, int N) {
   lbm_bgk_params prm{};
   prm.omega = 1.0 / kTau;
   prm.delta_form = 1;
+  prm.form = a.form;
   lbm_bc bc = global_bc();
   struct Slab {
     int R = 0, row0 = 0;
@@ -435,6 +439,15 @@ int main(int argc, char** argv) {
   a.slab_rows = arg_value(argc, argv, "--slab-rows", "");
   a.costs = arg_value(argc, argv, "--costs", "");
   a.uniform = std::atoi(arg_value(argc, argv, "--uniform", "0").c_str());
+  {
+    const std::string f = arg_value(argc, argv, "--form", "");
+    if (f == "reassociated") a.form = LBM_FORM_REASSOCIATED;
+    else if (f == "reference") a.form = LBM_FORM_REFERENCE_ORDER;
+    else if (!f.empty()) {
+      std::fprintf(stderr, "--form reference|reassociated\n");
+      return 2;
+    }
+  }
   a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.diameter = std::atoi(arg_value(argc, argv, "--diameter", "300").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());

@@ -234,6 +234,20 @@ def test_slab_ring_cylinder_emulated_chain_with_the_cylinder_on_a_seam(tmp_path)
     assert roles == [(1, 0, 1), (1, 1, 0), (0, 0, 0), (0, 0, 0)], roles
 
 
+def test_slab_ring_cylinder_emulated_chain_with_the_reassociated_collision(tmp_path):
+    """--form reassociated (lbm_bgk_params.form on every slab and on the single block): the cylinder on the seam, both
+    co-owners; slabs == the single block bit for bit in this operation order too"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_cylinder")
+    r = subprocess.run([exe, "--emulate", "4", "--uniform", "1", "--rows", "96", "--cols", "160", "--diameter", "30", "--steps", "15",
+                        "--warmup", "5", "--check", "1", "--form", "reassociated"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["check"] == "bitwise equal to one block"
+    r = subprocess.run([exe, "--emulate", "2", "--form", "fast"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "--form" in r.stderr
+
+
 def test_slab_ring_cylinder_emulated_chain_with_planned_slab_heights(tmp_path):
     """the default: the LIBRARY cuts the domain (lbm_slab_ibm_plan_rows) -- the forced band lands inside ONE short slab,
     nobody straddles; == the single block bit for bit"""
