@@ -188,8 +188,10 @@ int lbm_slab_ibm_plan_rows(int* rows_out, int n_slabs, int rows_global, int cols
               "lbm_slab_ibm_plan_rows: bad argument");
   const int N = n_slabs, Rg = rows_global, D = depth, hmin_any = 4 * D + 8;
   LBM_REQUIRE(Rg >= N * hmin_any, "lbm_slab_ibm_plan_rows: %d rows cannot be cut into %d slabs of at least %d", Rg, N, hmin_any);
-  const double far = costs ? costs[0] : 0.1855 * (cols / 4096.0) * (D / 5.0);
-  const double oc0 = costs ? costs[1] : 76.0 * D, oc1 = costs ? costs[2] : 0.30 * far;
+  // built-in table, re-fitted at the end of round 3 on emulated 8-slab chains (profiles/r03_cylinder_emulated_8_slabs_forms.txt):
+  // far slabs 0.180 us per row; owner 394.7 us at 316 rows, 472.8 us at 884 rows = 351 us + 0.1375 us per row
+  const double far = costs ? costs[0] : 0.180 * (cols / 4096.0) * (D / 5.0);
+  const double oc0 = costs ? costs[1] : 70.2 * D, oc1 = costs ? costs[2] : 0.764 * far;
   auto equal = [&](int total, int k, int* out) {  // k heights that differ by at most one row
     for (int i = 0; i < k; ++i) out[i] = total / k + (i < total % k ? 1 : 0);
   };

@@ -448,8 +448,9 @@ int main(int argc, char** argv) {
       return 2;
     }
     // the planner's table is measured with the reference-order collision; the reassociated one walks a far row in
-    // 0.142 us instead of 0.1855 (4096 columns, 5 steps): scale the far-row terms unless --costs says otherwise
-    if (a.form == LBM_FORM_REASSOCIATED && a.costs.empty()) a.costs = "0.142,380,0.043";
+    // 0.157 us instead of 0.180 (4096 columns, 5 steps) and its owner block costs 326 us + 0.12 us per row: unless
+    // --costs says otherwise
+    if (a.form == LBM_FORM_REASSOCIATED && a.costs.empty()) a.costs = "0.157,326,0.12";
   }
   a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.diameter = std::atoi(arg_value(argc, argv, "--diameter", "300").c_str());

@@ -38,8 +38,8 @@ def test_baseline_geometry_puts_the_band_into_one_short_slab(lib):
     k = int(np.searchsorted(starts, v0, side="right") - 1)
     assert starts[k] <= v0 and v1 <= starts[k + 1]                              # inside ONE slab
     assert rows[k] == min(rows) and rows[k] < 16384 // 8
-    far = 0.1855
-    uniform = 76.0 * 5 + far * 2048            # an equal cut leaves an owner with 2048 rows AND the chain
+    far = 0.180                                # the built-in table (capi_slab_ibm.hip, re-fitted at the end of round 3)
+    uniform = 70.2 * 5 + far * 2048            # an equal cut leaves an owner with 2048 rows AND the chain
     assert pred < 0.8 * uniform
     assert max(r for i, r in enumerate(rows) if i != k) * far <= pred + 1e-9    # nobody slower than the prediction
 
