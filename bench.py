@@ -7,6 +7,13 @@ slab-decomposed along rows over N GPUs (weak scaling) with a halo exchange per l
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --gpus N ...          (no WORLD_SIZE in the environment: starts its N ranks itself)
 
+N > 1, either way: every rank process is a SUPERVISOR that never touches the GPU and runs the benchmark in a WORKER
+child of its own.  Workers report stages ("ring_up", "timed", "done") through a file; the supervisors agree over gloo:
+a rank that has not brought its ring up within --ring-deadline seconds (an RCCL initialisation or first exchange that
+hangs) makes every supervisor end its worker (exact pid) and start a FRESH one on the peer-mapped transport with the
+gloo control plane -- no RCCL anywhere --, and the line then carries `launcher.transport_fallback`; a run that has
+no line after --launch-timeout seconds ends non-zero with the stalled rank's stderr instead of a time-limit kill.
+
 One step = one pass of the hot path over every node of the box (the default launch fuses 5
 steps: `steps` counts time steps, not launches).  Rank 0 prints ONE JSON line.
 
@@ -84,8 +91,8 @@ def self_launch(a, argv):
         bad = [r for r, (p, _, _) in enumerate(procs) if p.poll() not in (None, 0)]
         if bad:
             why = f"rank {bad[0]} exited with code {procs[bad[0]][0].returncode}"
-        elif time.time() - t0 > a.launch_timeout:
-            why = f"no result after {a.launch_timeout} s"
+        elif time.time() - t0 > a.launch_timeout + 60:     # the supervisors enforce --launch-timeout themselves; this is the outer guard
+            why = f"no result after {a.launch_timeout + 60} s"
         if why:
             for p, _, _ in procs:
                 if p.poll() is None:
@@ -116,6 +123,165 @@ def self_launch(a, argv):
         return 1
     print(lines[-1], flush=True)
     return 0
+
+
+# =====================================================================================================
+# supervisor: one per rank (under torch.distributed.run or self_launch alike); the benchmark itself runs in a worker
+# child, so a hang in RCCL (communicator initialisation, first exchange) costs one deadline, not the run
+# =====================================================================================================
+STAGES = ["spawned", "start", "ring_up", "timed", "done"]
+
+
+def _stage_of(path):
+    try:
+        words = open(path).read().split()
+    except OSError:
+        return 0
+    return max([STAGES.index(w) for w in words if w in STAGES] or [0])
+
+
+def _end_process(p, grace=10.0):
+    """terminate, then kill, the exact child we started"""
+    if p.poll() is None:
+        p.terminate()
+        t1 = time.time()
+        while p.poll() is None and time.time() - t1 < grace:
+            time.sleep(0.05)
+        if p.poll() is None:
+            p.kill()
+    p.wait()
+
+
+def _strip_args(argv, names_with_value=(), flags=()):
+    out, i = [], 0
+    while i < len(argv):
+        if argv[i] in names_with_value:
+            i += 2
+        elif any(argv[i].startswith(n + "=") for n in names_with_value) or argv[i] in flags:
+            i += 1
+        else:
+            out.append(argv[i])
+            i += 1
+    return out
+
+
+def supervise(a, argv):
+    """Returns the exit code.  Never initialises the GPU (torch.cuda.device_count() does not)."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if world != a.gpus:
+        print(f"--gpus {a.gpus} but WORLD_SIZE={world}: either launch N ranks (torch.distributed.run) or unset WORLD_SIZE "
+              "and let bench.py start them", file=sys.stderr)
+        return 2
+    n_dev = torch.cuda.device_count()
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not a.share_gpu and local_rank >= n_dev:
+        print(f"rank {rank}: LOCAL_RANK {local_rank} but {n_dev} GPU(s) visible (one rank per GPU; --share-gpu puts every rank "
+              "on GPU 0 for a rehearsal)", file=sys.stderr)
+        return 2
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    t_run = time.time()
+    box = [tempfile.mkdtemp(prefix="lbm_bench_sup_", dir="/tmp") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    base = box[0]
+    first = "ipc" if a.share_gpu else a.transport
+    plan = [(first, "gloo" if (a.share_gpu or a.ctl == "gloo") else "nccl")]
+    if not a.no_fallback:
+        plan.append(("ipc", "gloo"))         # the second attempt uses no RCCL at all
+    worker_argv = _strip_args(argv, names_with_value=("--transport", "--ctl"))
+    script = a.worker_script or os.path.abspath(__file__)
+    history, code, line = [], 1, None
+    for attempt, (transport, ctlb) in enumerate(plan):
+        port = [0]
+        if rank == 0:
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0))
+                port[0] = s_.getsockname()[1]
+        dist.broadcast_object_list(port, src=0)
+        stem = os.path.join(base, f"a{attempt}_rank{rank}")
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k != "GLOO_SOCKET_IFNAME"}
+        env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port[0]), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        open(stem + ".stage", "w").write("spawned\n")
+        with open(stem + ".out", "w") as fo, open(stem + ".err", "w") as fe:
+            proc = subprocess.Popen([sys.executable, script] + worker_argv +
+                                    ["--worker", "--status-file", stem + ".stage", "--transport", transport, "--ctl", ctlb,
+                                     "--attempt", str(attempt)], env=env, stdout=fo, stderr=fe)
+        t0, verdict, table = time.time(), None, None
+        while verdict is None:
+            time.sleep(0.2)
+            rc = proc.poll()
+            mine = [float(_stage_of(stem + ".stage")), 0.0 if rc is None else (1.0 if rc == 0 else 2.0), 0.0, 0.0]
+            if rank == 0:                               # rank 0's clock decides for everybody
+                mine[2] = float(time.time() - t0 > a.ring_deadline)
+                mine[3] = float(time.time() - t_run > a.launch_timeout)
+            t = torch.tensor(mine, dtype=torch.float64)
+            rows = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(rows, t)
+            table = [r_.tolist() for r_ in rows]
+            stages = [int(r_[0]) for r_ in table]
+            failed = [i for i, r_ in enumerate(table) if r_[1] == 2.0]
+            late = [i for i, st in enumerate(stages) if st < STAGES.index("ring_up")]
+            if all(r_[1] == 1.0 for r_ in table):
+                verdict = ("ok", None)
+            elif failed:
+                verdict = ("failed", f"rank {failed[0]} exited with an error at stage '{STAGES[stages[failed[0]]]}'", failed[0])
+            elif table[0][3] > 0:
+                slow = min(range(world), key=lambda i: stages[i])
+                verdict = ("timeout", f"no result {a.launch_timeout:.0f} s after the start (rank {slow} at stage '{STAGES[stages[slow]]}')", slow)
+            elif table[0][2] > 0 and late:
+                # (a rank that waits in a collective for a stalled peer is late too: every late rank is named)
+                verdict = ("ring_deadline", f"rank(s) {late} had not brought the ring up {a.ring_deadline:.0f} s after the workers started "
+                                            f"(stages {[STAGES[stages[i]] for i in late]})", late[0], late)
+        if verdict[0] == "ok":
+            proc.wait()
+            code = 0
+            if rank == 0:
+                lines = [ln for ln in open(stem + ".out").read().splitlines() if ln.startswith("{")]
+                line = lines[-1] if lines else None
+                sys.stderr.write(open(stem + ".err").read()[-2000:])
+            break
+        _end_process(proc)
+        dist.barrier()                                  # every worker of this attempt is gone before the next set starts
+        history.append({"attempt": attempt, "transport": transport, "control_plane": ctlb, "gave_up": verdict[1]})
+        before_ring = verdict[0] == "ring_deadline" or (verdict[0] == "failed" and int(table[verdict[2]][0]) < STAGES.index("ring_up"))
+        if verdict[0] == "timeout" or not before_ring or attempt + 1 == len(plan):
+            if rank == 0:
+                print(f"bench.py --gpus {world}: {verdict[1]}", file=sys.stderr)
+                for r_ in (verdict[3] if len(verdict) > 3 else [verdict[2]]):
+                    err = ""
+                    try:
+                        err = open(os.path.join(base, f"a{attempt}_rank{r_}.err")).read()[-(4000 // max(1, len(verdict[3]) if len(verdict) > 3 else 1)):]
+                    except OSError:
+                        pass
+                    print(f"---- stderr of rank {r_} (attempt {attempt}, transport {transport}) ----\n{err}", file=sys.stderr)
+                sys.stderr.flush()
+            code = 1
+            break
+        if rank == 0:
+            print(f"bench.py: {verdict[1]}; starting fresh workers on the peer-mapped transport (gloo control plane)", file=sys.stderr, flush=True)
+    if code == 0 and rank == 0:
+        if not line:
+            print("bench.py: rank 0's worker printed no result line", file=sys.stderr)
+            code = 1
+        else:
+            out = json.loads(line)
+            out["launcher"] = {"supervised": True, "attempts": len(history) + 1, "ring_deadline_s": a.ring_deadline,
+                               "run_s": round(time.time() - t_run, 1)}
+            if history:
+                out["launcher"]["transport_fallback"] = history
+            print(json.dumps(out), flush=True)
+            if box_failed(out, 0):
+                code = 3
+    flag = [code]
+    dist.broadcast_object_list(flag, src=0)
+    dist.destroy_process_group()
+    return flag[0]
 
 
 # =====================================================================================================
@@ -201,18 +367,75 @@ def cpu_baseline(rows=1024, cols=1024, budget_s=15.0):
         return dict(value=round(rows * cols * n / dt / 1e6, 3), unit="MLUPS", cores=threads,
                     sample=f"{rows}x{cols} periodic BGK f64, {n} steps in {dt:.1f} s")
 
-    port = timed(orc.bgk_periodic_steps, orc.max_threads())
+    all_threads = orc.max_threads()
+    port = timed(orc.bgk_periodic_steps, all_threads)
     port["kind"] = "port"
+    # the restatement on ONE core beside all cores (the OpenMP team is resized in place)
+    budget_s = min(budget_s, 6.0)
+    orc.set_threads(1)
+    try:
+        port["one_core"] = timed(orc.bgk_periodic_steps, 1)
+    finally:
+        orc.set_threads(all_threads)
     out = port
     if Ref.available():
         try:
             ref = Ref()
+            budget_s = 15.0
             out = timed(ref.bgk_periodic_steps, ref.num_threads())
             out["kind"] = "reference"
             out["port"] = port
         except OSError as e:  # libtorch not loadable on this host
             out["note"] = f"oracle/_ref unusable: {e}"
     return out
+
+
+def cpu_secondary(which, budget_s=6.0):
+    """CPU figure beside a secondary workload (C3 at 1024^2, C4 at 512 x 256, C5 at 2048 x 512): the
+    OpenMP restatement on all host cores and, for KBC, the unmodified reference's `kbc` (oracle/_ref) beside it.
+    Checker code, after the timed regions, bounded to a few seconds each."""
+    import numpy as np
+    from pyoracle import Oracle, Ref, cg_params
+    orc = Oracle()
+    cores = orc.max_threads()
+
+    def timed(step_n, nodes, threads, what, kind):
+        step_n(1)
+        t0 = time.perf_counter(); step_n(2); per = (time.perf_counter() - t0) / 2
+        n = max(2, min(100, int(budget_s / max(per, 1e-6))))
+        t0 = time.perf_counter(); step_n(n); dt = time.perf_counter() - t0
+        return dict(value=round(nodes * n / dt / 1e6, 3), unit="MLUPS", cores=threads, kind=kind, sample=f"{what}, {n} steps in {dt:.1f} s")
+
+    if which == "kbc":
+        R = C = 1024
+        s2 = 1.0 / (0.5 + 3 * 1.70766666e-4)
+        m0, m1 = orc.kbc_shear_init(R, C)
+        f = orc.kbc_equilibrium(m0, m1)
+        out = timed(lambda n: orc.kbc_steps(f, m0, m1, s2, n), R * C, cores, f"{R}x{C} KBC shear layer f64", "port")
+        if Ref.available():
+            try:
+                ref = Ref()
+                r_ = timed(lambda n: ref.kbc_steps(f, m0, m1, s2, n), R * C, ref.num_threads(), f"{R}x{C} KBC shear layer f64 (ulbm::d2q9::kbc)", "reference")
+                r_["port"] = out
+                out = r_
+            except OSError as e:
+                out["note"] = f"oracle/_ref unusable: {e}"
+        return out
+    if which == "cg":
+        R, C = 512, 256
+        p = cg_params(R, C)
+        st = orc.cg_init(p)
+        return timed(lambda n: orc.cg_steps(p, st, n), R * C, cores, f"{R}x{C} colour-gradient two-phase MRT f64, gamma3 parameters", "port")
+    if which == "ibm":
+        R, C = 2048, 512
+        m = int(round(np.pi * 37.5))
+        t = 2 * np.pi * np.arange(m) / m
+        x, y = R / 4.0 + 18.75 * np.cos(t), C / 2.0 + 18.75 * np.sin(t)
+        u = np.zeros((R, C, 2)); u[..., 0] = 0.04
+        f = orc.incomp_equilibrium(u, np.ones((R, C)))
+        return timed(lambda n: orc.cylinder_steps(x, y, f, 1.0 / 0.55, 0.04, n), R * C, cores,
+                     f"{R}x{C} BGK + immersed cylinder (d = 37.5, {m} markers) f64", "port")
+    raise ValueError(which)
 
 
 class Box:
@@ -703,6 +926,36 @@ def run_secondary(lib, dev, which, a):
                                                           for k, v in pm["FETCH_SIZE"].items()}})
         except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
             out["roofline"]["traffic_source"] = f"PMC passes failed: {type(e).__name__}: {e}"
+        # the second roof (SURVEY 8(d) "which roofline": report both where the HBM fraction plateaus): f64 VALU issue.
+        # One SQ pass over the same launch groups: VALU wave-instructions x 64 lanes per update, against 256 CUs x 4 SIMDs x
+        # 16 lanes per clock at the shader clock sampled beside the same launches.  `bound` names the higher fraction.
+        try:
+            rows = _pmc_run_multi(["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"],
+                                  ["--pmc-child", which] + [x for kv in a.tune for x in ("--tune", kv)], 240)
+            marks = sorted({int(r["Dispatch_Id"]) for r in rows if "k_lbm_marker" in r["Kernel_Name"]})
+            if len(marks) != 2:
+                raise OSError(f"SQ pass of {which}: {len(marks)} markers in the trace")
+            acc = {}
+            for r in rows:
+                if marks[0] < int(r["Dispatch_Id"]) < marks[1]:
+                    acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            lane_ops = acc["SQ_INSTS_VALU"] * 64.0 / groups / (nodes * w.unit)
+            sclk = (power or {}).get("sclk_mhz") or 2400
+            ach_v = lane_ops * nodes * w.unit / (group_ms * 1e-3)
+            peak_v = 256 * 64 * sclk * 1e6
+            roof = out["roofline"]
+            roof["valu"] = {"lane_ops_per_update": round(lane_ops, 1), "achieved": round(ach_v / 1e12, 2), "peak": round(peak_v / 1e12, 2),
+                            "unit": "T lane-ops/s", "frac": round(ach_v / peak_v, 4), "sclk_mhz": sclk,
+                            "sclk_source": "rocm-smi beside the same launches" if (power or {}).get("sclk_mhz") else "nominal 2400 MHz (no sample)",
+                            "issue_frac_per_wave": round(acc["SQ_ACTIVE_INST_VALU"] / acc["SQ_WAVE_CYCLES"], 4),
+                            "source": "rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES pass of this run, every launch "
+                                      "between two marker kernels; peak = 256 CUs x 64 f64 lanes per clock x sclk"}
+            if roof.get("frac") is not None and roof["valu"]["frac"] > roof["frac"]:
+                roof["bound"] = "valu"
+                roof["bound_note"] = ("the f64 VALU issue fraction exceeds the HBM fraction: this kernel sits on the vector-ALU roof; "
+                                      "achieved / peak / frac above stay the HBM figures, roofline.valu holds the other roof")
+        except (subprocess.TimeoutExpired, OSError, KeyError, ValueError, ZeroDivisionError) as e:
+            out["roofline"]["valu"] = {"error": f"SQ pass failed: {type(e).__name__}: {e}"}
     return out
 
 
@@ -761,7 +1014,16 @@ def parse_args(argv):
                     help="slab ring transport: RCCL send/recv (default) or peer-mapped direct stores (hipIpc windows)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal: all N ranks on GPU 0 (peer-mapped transport, gloo control plane) -- checks the N-rank plumbing, not a scaling number")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks: seconds before the run is given up")
+    ap.add_argument("--launch-timeout", type=float, default=520.0,
+                    help="N > 1: seconds after which a run without a result line is given up (exit 1 with the stalled rank's stderr)")
+    ap.add_argument("--ring-deadline", type=float, default=120.0,
+                    help="N > 1: seconds a worker has to bring its slab ring up before every rank restarts on the peer-mapped transport")
+    ap.add_argument("--no-fallback", action="store_true", help="N > 1: no second attempt on the peer-mapped transport")
+    ap.add_argument("--ctl", choices=["nccl", "gloo"], default="nccl", help="control plane of the workers (barriers, reductions)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--status-file", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--attempt", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--worker-script", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--no-secondary", action="store_true", help="N = 1: skip configs 3 / 4 / 5 after the headline")
     ap.add_argument("--secondary", default="kbc,cg,ibm", help="which secondary workloads (N = 1)")
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi clock / power samples beside the workloads")
@@ -773,8 +1035,19 @@ def parse_args(argv):
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse_args(argv)
-    if "WORLD_SIZE" not in os.environ and a.gpus > 1 and not a.pmc_child:
-        sys.exit(self_launch(a, argv))
+    if a.gpus > 1 and not a.pmc_child and not a.worker:
+        if "WORLD_SIZE" not in os.environ:
+            sys.exit(self_launch(a, argv))
+        sys.exit(supervise(a, argv))
+
+    def stage(word):
+        if a.status_file:
+            with open(a.status_file, "a") as fh:
+                fh.write(word + "\n")
+    stage("start")
+    stall = os.environ.get("LBM_BENCH_STALL")      # fault injection (tests): "rank:attempt" never brings its ring up
+    if stall and a.worker and stall == f"{os.environ.get('RANK', '0')}:{a.attempt}":
+        time.sleep(3600)
 
     import torch
     import pylbm
@@ -793,7 +1066,7 @@ def main(argv=None):
                          "--share-gpu puts every rank on GPU 0 for a rehearsal)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    ctl = Ctl(rank, world, dev, "gloo" if a.share_gpu else "nccl")
+    ctl = Ctl(rank, world, dev, "gloo" if (a.share_gpu or a.ctl == "gloo") else "nccl")
 
     lib = pylbm.Lib()
     lib.set_device(local_rank)
@@ -817,6 +1090,9 @@ def main(argv=None):
     f0 = taylor_green(lib, torch, _ptr, R, C, rank * R, world * R, dev)
     box.load(f0)
     del f0
+    torch.cuda.synchronize()
+    ctl.barrier()
+    stage("ring_up")        # communicators initialised, ring created, first halo exchange done -- on every rank
 
     # -- slab ring: the one-exchange-per-`period`-launches schedule against one exchange per launch, here and now ----
     # (if the two ever differ on this machine, the timed run falls back to the plain schedule and says so)
@@ -858,6 +1134,7 @@ def main(argv=None):
     mid = order[repeats // 2]
     dt, dev_ms = wall[mid], devms[mid]
 
+    stage("timed")
     mass = ctl.reduce([float(box.owned().sum())], "sum")[0]
     ring_status = int(ctl.reduce([float(lib.raw.lbm_ring_status(box.ring) != 0)], "max")[0]) if box.ring else 0
 
@@ -1019,8 +1296,16 @@ def main(argv=None):
             out["secondary"] = sec
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            for ent, w in zip(out.get("secondary", []), [x for x in a.secondary.split(",") if x]):
+                try:
+                    ent["cpu_baseline"] = cpu_secondary(w)
+                    if ent.get("value") and ent["cpu_baseline"].get("value"):
+                        ent["cpu_baseline"]["gpu_over_cpu"] = round(ent["value"] / ent["cpu_baseline"]["value"], 1)
+                except Exception as e:  # a baseline must never cost the line
+                    ent["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     ctl.close()
+    stage("done")
     if box_failed(out, rank):
         sys.exit(3)
 

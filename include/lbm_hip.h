@@ -444,8 +444,15 @@ int lbm_ring_create_ex(lbm_ring** out, const unsigned char* id128, int rank, int
 int lbm_ring_destroy(lbm_ring* rg);
 int lbm_ring_transport(const lbm_ring* rg); /* LBM_RING_RCCL or LBM_RING_IPC */
 /* LBM_OK, or LBM_ERR_STATE once a bounded wait of the peer-mapped transport has given up on a neighbour
- * (tuning "ring_ipc_timeout_ms", default 20000): everything computed since is void.  Host-side read, no sync. */
+ * (tuning "ring_ipc_timeout_ms", default 20000; the failure is sticky: every later wait of the queue returns at
+ * once, copies are skipped, nothing more is announced) or once RCCL has reported an asynchronous error
+ * (ncclCommGetAsyncError; such a communicator is aborted at lbm_ring_destroy): everything computed since is
+ * void.  Host-side read, no sync; meant for once per batch of launches. */
 int lbm_ring_status(const lbm_ring* rg);
+/* 1 if the peer-mapped transport's receive window lives in ordinary cached device memory: the runtime refused the
+ * uncached allocation and the caller had accepted that beforehand (lbm_set_tuning("ring_ipc_cached_ok", 1));
+ * without that tuning lbm_ring_create_ex fails instead.  0 otherwise (and for RCCL). */
+int lbm_ring_window_cached(const lbm_ring* rg);
 /* refresh the ghost rows of `lattice` (ordered after the work enqueued on `after`); asynchronous */
 int lbm_ring_exchange(lbm_ring* rg, double* lattice, lbm_stream_t after);
 /* same with complete ghost rows (LBM_HALO_FULL): the initial fill before multi-step launches on a

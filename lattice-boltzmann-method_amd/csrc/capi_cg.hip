@@ -102,8 +102,24 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   }
   rc.ic1 = (g.C - 3) / TC;  // last tile column with c_base + TC + 1 <= C - 2
   if (rc.ic1 > tiles_c) rc.ic1 = tiles_c;
-  const bool split = tuning("cg_split", 1) != 0 && rc.ir1 - rc.ir0 >= 1 && rc.ic1 - rc.ic0 >= 1;
+  bool split = tuning("cg_split", 1) != 0 && rc.ir1 - rc.ir0 >= 1 && rc.ic1 - rc.ic0 >= 1;
   g_last_inner_form = 0;
+  // several nodes per thread (k_cg_tile_mn): the inner rectangle is cut into BIG tiles from its top-left corner, what does
+  // not fill a big tile joins the frame.  100 + shape; shapes: {rows, columns, threads, waves per SIMD the registers are budgeted for}
+  const int big = TR == 16 && TC == 32 ? tuning("cg_big", 0) : 0;
+  static const int big_shapes[][4] = {{32, 32, 512, 4}, {16, 64, 512, 4}, {16, 128, 1024, 4}, {32, 64, 1024, 4},
+                                      {32, 64, 512, 2}, {8, 64, 512, 4}, {16, 64, 1024, 4}, {16, 128, 512, 2}};
+  int n_btr = 0, n_btc = 0;
+  if (split && big >= 1 && big <= (int)(sizeof big_shapes / sizeof big_shapes[0])) {
+    const int* s = big_shapes[big - 1];
+    const int rows16 = ((rc.ir1 - rc.ir0) * 16 / s[0]) * s[0] / 16 * 16;  // rows the big tiles cover: whole big tiles AND whole 16-row units
+    n_btr = rows16 / s[0];
+    n_btc = (rc.ic1 - rc.ic0) * 32 / s[1];
+    if (n_btr >= 1 && n_btc >= 1 && n_btr * s[0] == rows16 && (n_btc * s[1]) % 32 == 0) {
+      rc.ir1 = rc.ir0 + rows16 / 16;
+      rc.ic1 = rc.ic0 + n_btc * s[1] / 32;
+    } else n_btr = n_btc = 0;
+  }
   if (!split) {
     if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
     else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
@@ -129,7 +145,26 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 2>), dim3(frame), dim3(TR * TC), 0, fs, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
     LBM_CHECK_LAUNCH();
   }
-  const int sw4 = tuning("cg_strip2", 0);
+  const int sw4 = n_btr ? 0 : tuning("cg_strip2", 0);
+  if (n_btr) {  // k_cg_tile_mn: big tiles, several nodes per thread
+    const int ra = row_begin + rc.ir0 * TR, ca = rc.ic0 * TC, nt = n_btr * n_btc;
+    const int bx = tuning("cg_big_xcd", 2);
+    g_last_inner_form = 100 + big;
+#define LBM_CG_BIG(BR, BC, BT, BM, BP)                                                                               \
+    if (psi) LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, true>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx); \
+    else LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, false>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx);
+    switch (big) {
+      case 1: LBM_CG_BIG(32, 32, 512, 4, true) break;    // 2 nodes per thread, the second parked in LDS: 2 workgroups per CU
+      case 2: LBM_CG_BIG(16, 64, 512, 4, true) break;
+      case 3: LBM_CG_BIG(16, 128, 1024, 4, true) break;  // 1024 threads: one workgroup per CU
+      case 4: LBM_CG_BIG(32, 64, 1024, 4, true) break;
+      case 5: LBM_CG_BIG(32, 64, 512, 2, false) break;   // 4 nodes per thread, 2 waves per SIMD: one workgroup per CU
+      case 6: LBM_CG_BIG(8, 64, 512, 4, false) break;    // one node per thread in the wide shape (what the width alone is worth)
+      case 7: LBM_CG_BIG(16, 64, 1024, 4, false) break;
+      default: LBM_CG_BIG(16, 128, 512, 2, false) break;
+    }
+#undef LBM_CG_BIG
+  } else
   // 41 .. 47: k_cg_walk -- a workgroup of TR x WC waves walking down a strip of 64 WC - 4 columns, TR rows a step
   if (sw4 >= 41 && sw4 <= 47 && rc.ic0 * TC >= 4 && 9.0 * (double)g.plane * 8.0 < 4.0e9) {  // 32-bit plane offsets
     const int ra = row_begin + rc.ir0 * TR, rb = row_begin + rc.ir1 * TR, ca = rc.ic0 * TC, cb = rc.ic1 * TC;

@@ -49,8 +49,10 @@ static void tuning_from_env() {
 }
 
 // Launch paths read 6-10 keys per launch: the table itself (a map under a mutex) is consulted only when lbm_set_tuning has
-// run since this thread last looked the key up -- otherwise the answer comes from a small thread-local cache keyed by the
-// call site's string literal (pointer identity; a version counter invalidates every cache at once).
+// run since this thread last looked the key up -- otherwise the answer comes from a small thread-local cache.  A slot is
+// found by the address of the key and CONFIRMED by its content (an inline copy of the name): a key built in a buffer, or
+// storage reused for another name, misses instead of returning another key's value.  A version counter
+// invalidates every cache at once.
 static std::atomic<unsigned> g_tune_version{1};
 
 int tuning(const char* key, int dflt) {
@@ -59,16 +61,22 @@ int tuning(const char* key, int dflt) {
     unsigned version;
     int value;
     bool present;
+    char name[40];
   };
   thread_local Slot cache[128] = {};
   Slot& sl = cache[(reinterpret_cast<uintptr_t>(key) >> 3) & 127];
   const unsigned ver = g_tune_version.load(std::memory_order_acquire);
-  if (sl.key == key && sl.version == ver) return sl.present ? sl.value : dflt;
+  if (sl.key == key && sl.version == ver && std::strncmp(sl.name, key, sizeof sl.name) == 0) return sl.present ? sl.value : dflt;
   std::lock_guard<std::mutex> lk(g_tune_mu);
   tuning_from_env();
   auto it = g_tune.find(key);
-  sl = Slot{key, ver, it == g_tune.end() ? 0 : it->second, it != g_tune.end()};
-  return sl.present ? sl.value : dflt;
+  const bool fits = std::strlen(key) < sizeof sl.name;  // longer names are never cached (none exists)
+  sl.key = fits ? key : nullptr;
+  sl.version = ver;
+  sl.value = it == g_tune.end() ? 0 : it->second;
+  sl.present = it != g_tune.end();
+  std::strncpy(sl.name, fits ? key : "", sizeof sl.name);
+  return it == g_tune.end() ? dflt : it->second;
 }
 
 // ---- layout converters -------------------------------------------------------------------

@@ -39,6 +39,9 @@ struct Rccl {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (checked once per batch by lbm_ring_status; absent in a very old runtime: then the status stays LBM_OK)
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
 };
 
 Rccl g_rccl;
@@ -72,6 +75,8 @@ int load_rccl() {
   LBM_SYM(GroupEnd, "ncclGroupEnd")
   LBM_SYM(GetErrorString, "ncclGetErrorString")
 #undef LBM_SYM
+  *(void**)(&g_rccl.CommGetAsyncError) = dlsym(h, "ncclCommGetAsyncError");
+  *(void**)(&g_rccl.CommAbort) = dlsym(h, "ncclCommAbort");
   g_rccl.h = h;
   return LBM_OK;
 }
@@ -105,6 +110,7 @@ struct lbm_ring {
   int valid;                     // ghost rows per side known to be current (set by an exchange, used up by launches without one)
   int profile;
   hipEvent_t t_edge0, t_edge1, t_xchg1, t_main0, t_main1;
+  int rccl_failed;               // ncclCommGetAsyncError has reported an error: the communicator is aborted, not destroyed
 };
 
 using namespace lbm;
@@ -203,15 +209,36 @@ int lbm_ring_create(lbm_ring** out, const unsigned char* id128, int rank, int nr
 
 int lbm_ring_transport(const lbm_ring* rg) { return rg ? rg->transport : LBM_ERR_INVALID; }
 
-// 0 while every message has arrived; the peer-mapped transport's bounded waits report here when a neighbour
-// never delivered (1) or never acknowledged (2) -- the launch chain still drains, its results are void
+// 0 while every message has arrived.  Peer-mapped transport: its bounded waits report here when a neighbour never
+// delivered (1) or never acknowledged (2) -- the launch chain still drains, its results are void.  RCCL:
+// ncclCommGetAsyncError (a failed peer, a broken link: errors RCCL detects asynchronously and that no launch call
+// returns); meant to be read once per batch of launches, not per step.
 int lbm_ring_status(const lbm_ring* rg) {
   LBM_REQUIRE(rg, "lbm_ring_status: NULL ring");
+  if (rg->transport == LBM_RING_RCCL) {
+    if (rg->rccl_failed) {
+      set_error("lbm_ring: RCCL reported an asynchronous error on rank %d earlier", rg->rank);
+      return LBM_ERR_STATE;
+    }
+    if (rg->comm && g_rccl.CommGetAsyncError) {
+      ncclResult_t async = 0;
+      const ncclResult_t r = g_rccl.CommGetAsyncError(rg->comm, &async);
+      const int kNcclInProgress = 7;
+      if (r != 0 || (async != 0 && async != kNcclInProgress)) {
+        const_cast<lbm_ring*>(rg)->rccl_failed = 1;
+        set_error("lbm_ring: RCCL asynchronous error on rank %d: %s", rg->rank, g_rccl.GetErrorString(r != 0 ? r : async));
+        return LBM_ERR_STATE;
+      }
+    }
+    return LBM_OK;
+  }
   const int st = rg->ipc ? ipc_status(rg->ipc) : 0;
   if (st) set_error("lbm_ring: a neighbour of rank %d never %s within the time limit (\"ring_ipc_timeout_ms\")", rg->rank,
                     st == 1 ? "delivered its message" : "acknowledged a message");
   return st ? LBM_ERR_STATE : LBM_OK;
 }
+
+int lbm_ring_window_cached(const lbm_ring* rg) { return rg && rg->ipc ? ipc_window_cached(rg->ipc) : 0; }
 
 int lbm_ring_destroy(lbm_ring* rg) {
   if (!rg) return LBM_OK;
@@ -228,7 +255,9 @@ int lbm_ring_destroy(lbm_ring* rg) {
     (void)hipStreamDestroy(rg->aux);
   }
   if (rg->edge) (void)hipStreamDestroy(rg->edge);
-  if (rg->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(rg->comm);
+  // a communicator with an asynchronous error is aborted: ncclCommDestroy would wait for its outstanding operations
+  if (rg->comm && rg->rccl_failed && g_rccl.CommAbort) (void)g_rccl.CommAbort(rg->comm);
+  else if (rg->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(rg->comm);
   if (rg->ipc) ipc_destroy(rg->ipc);
   delete rg;
   return LBM_OK;
@@ -747,12 +776,19 @@ static int ring_pressure_start(lbm_ring* rg, lbm_slab_pressure* sl, double* post
                    : lbm_slab_pressure_start_finish(sl, post, pre, buf[1], buf[3], main_s);
   if (!rc && m0) {  // KBC: the collision on held moments left the ghost rows of `post` behind: complete halos over every seam
     rc = ring_exchange(rg, post, nullptr, main, true);
-    if (!rc) {
-      LBM_CHECK_HIP(hipEventRecord(rg->edge_done, rg->edge));
-      LBM_CHECK_HIP(hipStreamWaitEvent(main, rg->edge_done, 0));
+    if (!rc) {  // (errors become rc: the common tail below still syncs and frees the four start-up buffers)
+      hipError_t ej = hipEventRecord(rg->edge_done, rg->edge);
+      if (ej == hipSuccess) ej = hipStreamWaitEvent(main, rg->edge_done, 0);
+      if (ej != hipSuccess) {
+        set_error("lbm_ring_pressure_start: %s", hipGetErrorString(ej));
+        rc = LBM_ERR_HIP;
+      }
     }
   }
-  if (!rc && hipStreamSynchronize(main) != hipSuccess) {
+  // the start-up buffers are freed below: nothing enqueued on them may still be running -- on the error paths too
+  hipError_t es = hipStreamSynchronize(main);
+  if (es == hipSuccess && rg->edge) es = hipStreamSynchronize(rg->edge);
+  if (!rc && es != hipSuccess) {
     set_error("lbm_ring_pressure_start: stream synchronisation failed");
     rc = LBM_ERR_HIP;
   }

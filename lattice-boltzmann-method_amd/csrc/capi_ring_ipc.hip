@@ -52,9 +52,14 @@ struct Rendezvous {  // POSIX shared memory, zero-filled by the kernel when firs
 __device__ inline uint64_t load_sys(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline void store_sys(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// ONE wave; lane 0 polls until *flag >= want or `limit` wall-clock ticks have passed
+__device__ inline int status_sys(const int* status) { return __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// ONE wave; lane 0 polls until *flag >= want or `limit` wall-clock ticks have passed.  The failure is STICKY: once the
+// status word is raised (by this or an earlier wait) every later wait of the queue returns at once, so a queue of N
+// launches behind a dead neighbour drains in ONE time limit, not in 4 N of them.
 __global__ __launch_bounds__(64) void k_ipc_wait(const uint64_t* flag, uint64_t want, unsigned long long limit, int* status, int code) {
   if (threadIdx.x == 0) {
+    if (status_sys(status) != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (load_sys(flag) < want) {
       __builtin_amdgcn_s_sleep(16);
@@ -67,29 +72,34 @@ __global__ __launch_bounds__(64) void k_ipc_wait(const uint64_t* flag, uint64_t 
   }
 }
 
-// the last workgroup to arrive publishes `seq` (every store / load of this launch has completed by then)
-__device__ inline void publish_when_all_done(uint64_t* word, uint64_t seq, unsigned* arrived) {
+// the last workgroup to arrive publishes `seq` (every store / load of this launch has completed by then) -- unless the
+// ring has failed: then nothing is announced (a slot that was not filled must not be read as a message)
+__device__ inline void publish_when_all_done(uint64_t* word, uint64_t seq, unsigned* arrived, const int* status) {
   __atomic_thread_fence(__ATOMIC_RELEASE);  // system scope: this wave's accesses have drained
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned n = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     if (n + 1 == gridDim.x) {
       __hip_atomic_store(arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      // the status word never returns to 0: if it is 0 now, every workgroup of this launch saw 0 and copied
+      if (status_sys(status) == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
 
+// after a failed wait the copies are skipped too (the data is void either way; the queue only has to drain)
 __global__ __launch_bounds__(256) void k_ipc_put(uint64_t* __restrict__ remote, const uint64_t* __restrict__ local, size_t n,
-                                                 uint64_t* remote_seq, uint64_t seq, unsigned* arrived) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) store_sys(remote + i, local[i]);
-  publish_when_all_done(remote_seq, seq, arrived);
+                                                 uint64_t* remote_seq, uint64_t seq, unsigned* arrived, const int* status) {
+  if (status_sys(status) == 0)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) store_sys(remote + i, local[i]);
+  publish_when_all_done(remote_seq, seq, arrived, status);
 }
 
 __global__ __launch_bounds__(256) void k_ipc_get(uint64_t* __restrict__ local, const uint64_t* __restrict__ slot, size_t n,
-                                                 uint64_t* remote_ack, uint64_t seq, unsigned* arrived) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) local[i] = load_sys(slot + i);
-  publish_when_all_done(remote_ack, seq, arrived);
+                                                 uint64_t* remote_ack, uint64_t seq, unsigned* arrived, const int* status) {
+  if (status_sys(status) == 0)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) local[i] = load_sys(slot + i);
+  publish_when_all_done(remote_ack, seq, arrived, status);
 }
 
 }  // namespace
@@ -102,6 +112,7 @@ struct IpcTransport {
   bool peer_opened[2];                 // mapped by hipIpcOpenMemHandle (not my own, not shared with the other side)
   uint64_t tx[2], rx[2];               // messages sent to / received from each side so far
   unsigned* arrived;                   // [4] arrival counters of the put / get launches (device)
+  bool window_cached;                  // the uncached allocation was refused and the caller accepted a cached window
   int* status_h;                       // pinned, mapped: first wait that gave up
   int* status_d;
   unsigned long long limit_ticks;
@@ -157,6 +168,7 @@ int ipc_create(IpcTransport** out, const unsigned char* id128, int rank, int nra
   t->window = nullptr;
   t->peer[0] = t->peer[1] = nullptr;
   t->peer_opened[0] = t->peer_opened[1] = false;
+  t->window_cached = false;
   t->tx[0] = t->tx[1] = t->rx[0] = t->rx[1] = 0;
   t->arrived = nullptr;
   t->status_h = t->status_d = nullptr;
@@ -166,10 +178,22 @@ int ipc_create(IpcTransport** out, const unsigned char* id128, int rank, int nra
     return rc;
   };
   const size_t bytes = kHeaderBytes + 4 * t->slot * sizeof(double);
-  // uncached: nothing of a window may linger in this GPU's L2 while a neighbour rewrites it
-  hipError_t e = hipExtMallocWithFlags((void**)&t->window, bytes, hipDeviceMallocUncached);
+  // uncached: nothing of a window may linger in this GPU's L2 while a neighbour rewrites it.  A runtime that refuses
+  // the uncached allocation fails the creation -- unless the caller has said that a cached window will do
+  // ("ring_ipc_cached_ok" = 1: every access to it is a system-scope access anyway; the uncached attribute is the second
+  // line of defence), and then the ring says so (lbm_ring_window_cached).  "ring_ipc_force_cached" = 1 skips the
+  // uncached attempt (tests).
+  hipError_t e = tuning("ring_ipc_force_cached", 0) ? hipErrorOutOfMemory
+                                                    : hipExtMallocWithFlags((void**)&t->window, bytes, hipDeviceMallocUncached);
   if (e != hipSuccess) {
     (void)hipGetLastError();
+    if (!tuning("ring_ipc_cached_ok", 0)) {
+      set_error("lbm_ring (peer-mapped transport): the uncached allocation of the receive window was refused (%s); "
+                "lbm_set_tuning(\"ring_ipc_cached_ok\", 1) accepts a cached window", hipGetErrorString(e));
+      t->window = nullptr;
+      return fail(LBM_ERR_HIP);
+    }
+    t->window_cached = true;
     e = hipMalloc((void**)&t->window, bytes);
   }
   if (e == hipSuccess) e = hipMemset(t->window, 0, kHeaderBytes);
@@ -268,6 +292,7 @@ int ipc_create(IpcTransport** out, const unsigned char* id128, int rank, int nra
 }
 
 int ipc_status(const IpcTransport* t) { return t && t->status_h ? *(volatile int*)t->status_h : 0; }
+int ipc_window_cached(const IpcTransport* t) { return t && t->window_cached ? 1 : 0; }
 
 int ipc_sendrecv(IpcTransport* t, const double* send_prev, size_t n_send_prev, double* recv_prev, size_t n_recv_prev,
                  const double* send_next, size_t n_send_next, double* recv_next, size_t n_recv_next, hipStream_t st) {
@@ -291,7 +316,7 @@ int ipc_sendrecv(IpcTransport* t, const double* send_prev, size_t n_send_prev, d
       const int o = 1 - s;  // I am on the neighbour's opposite side
       if (k > 2) LBM_KLAUNCH(k_ipc_wait, dim3(1), dim3(64), 0, st, seq_word(t->window, 1, s), k - 2, t->limit_ticks, t->status_d, 2);
       LBM_KLAUNCH(k_ipc_put, dim3(grid(len)), dim3(256), 0, st, slot_ptr(t->peer[s], t->slot, o, k),
-                  reinterpret_cast<const uint64_t*>(sbuf[s] + off), len, seq_word(t->peer[s], 0, o), k, t->arrived + s);
+                  reinterpret_cast<const uint64_t*>(sbuf[s] + off), len, seq_word(t->peer[s], 0, o), k, t->arrived + s, t->status_d);
     }
     for (int s = 0; s < 2; ++s) {
       const size_t off = c * t->slot;
@@ -300,7 +325,7 @@ int ipc_sendrecv(IpcTransport* t, const double* send_prev, size_t n_send_prev, d
       const uint64_t k = ++t->rx[s];
       LBM_KLAUNCH(k_ipc_wait, dim3(1), dim3(64), 0, st, seq_word(t->window, 0, s), k, t->limit_ticks, t->status_d, 1);
       LBM_KLAUNCH(k_ipc_get, dim3(grid(len)), dim3(256), 0, st, reinterpret_cast<uint64_t*>(rbuf[s] + off),
-                  slot_ptr(t->window, t->slot, s, k), len, seq_word(t->peer[s], 1, 1 - s), k, t->arrived + 2 + s);
+                  slot_ptr(t->window, t->slot, s, k), len, seq_word(t->peer[s], 1, 1 - s), k, t->arrived + 2 + s, t->status_d);
     }
   }
   LBM_CHECK_LAUNCH();

@@ -397,6 +397,110 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
                                            row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// ---- the tile kernel with SEVERAL NODES PER THREAD (round 4) ----------------------------------------------------------
+// Same structure as k_cg_fused MODE 1 (one barrier, independent workgroups), larger tile: a workgroup of NT threads covers
+// TR x TC nodes, NPT = TR TC / NT per thread (node n = thread + k NT, so a wave still reads whole rows), which cuts what
+// the 16 x 32 tile pays for its ring: rows fetched (TR + 6) / TR, 128-byte lines per row (TC / 16 + 2) / (TC / 16), ring
+// nodes reduced (TR + 4)(TC + 4) / (TR TC).  Between the barrier and its collision a node waits as 11 doubles (colour sums
+// + the two densities); u, 1 / rho are recomputed by the expressions of cg_node, psi comes back from the LDS tile: identical
+// bits.  The thread's nodes collide one after another (a scheduling barrier between them keeps the register count that of
+// one collision + 22 per waiting node).  PARK: the waiting nodes' colour sums wait in LDS instead (9 doubles per node, lane-major:
+// no conflicts, no barrier -- a thread reads back what it wrote), which is what lets two nodes per thread fit the 128
+// registers of four waves per SIMD without scratch.  Inner rectangle only: plain offsets, no clamps, no wraps (the frame
+// keeps k_cg_fused).
+template <int TR, int TC, int NT, int MINB, bool PARK, bool WITH_FIELDS>
+__global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
+    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
+    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
+    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
+    double* __restrict__ snu_out, MacroIdx mi, int ra, int ca, int tiles_c, int xcd_swizzle) {
+#pragma clang fp contract(on)
+  static_assert((TR * TC) % NT == 0 && NT % TC == 0, "whole rows per pass");
+  constexpr int NPT = TR * TC / NT, RPP = NT / TC, LR = TR + 4, LC = TC + 4, LDC = LC + 1;
+  __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
+  __shared__ double s_park[PARK ? NPT - 1 : 1][PARK ? Q : 1][PARK ? NT : 1];
+  int tile = blockIdx.x;
+  if (xcd_swizzle > 1) {  // groups of G column-neighbour tiles per XCD inside a common window (as k_cg_fused)
+    const int G = xcd_swizzle, x = tile % 8, m = tile / 8, win = 8 * G;
+    const int t2 = (m / G) * win + x * G + (m % G);
+    if ((m / G + 1) * win <= (int)gridDim.x) tile = t2;
+  } else if (xcd_swizzle == 1) {
+    const int per = gridDim.x / 8;
+    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+  }
+  const int r_base = ra + (tile / tiles_c) * TR, c_base = ca + (tile % tiles_c) * TC;
+  const int tr0 = threadIdx.x / TC, tc = threadIdx.x % TC;
+
+  double ft[PARK ? 1 : NPT][Q], rr[NPT], rb[NPT];
+#pragma unroll
+  for (int k = NPT - 1; k >= 0; --k) {  // node 0 last: it stays in registers
+    const int tr = tr0 + k * RPP;
+    double fk[Q];
+    const CgNode me = cg_node<true>(fk, in_r, in_b, g, Bc{}, cf, r_base + tr, c_base + tc);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      if (PARK && k > 0) s_park[k - 1][q][threadIdx.x] = fk[q];
+      else ft[PARK ? 0 : k][q] = fk[q];
+    }
+    rr[k] = me.rr;
+    rb[k] = me.rb;
+    s_psi[tr + 2][tc + 2] = me.psi;
+    s_qx[tr + 2][tc + 2] = me.qx;
+    s_qy[tr + 2][tc + 2] = me.qy;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  constexpr int NH = LR * LC - TR * TC;
+  for (int i = threadIdx.x; i < NH; i += NT) {  // the +-2 ring: two rows above, two below, then 2 + 2 columns beside each row
+    int lr, lc;
+    if (i < 2 * LC) {
+      lr = i / LC;
+      lc = i % LC;
+    } else if (i < 4 * LC) {
+      lr = TR + 2 + (i - 2 * LC) / LC;
+      lc = (i - 2 * LC) % LC;
+    } else {
+      const int j = i - 4 * LC;
+      lr = 2 + (j >> 2);
+      lc = (j & 3) < 2 ? (j & 3) : TC + (j & 3);
+    }
+    double tmp[Q];
+    const CgNode nb = cg_node<true>(tmp, in_r, in_b, g, Bc{}, cf, r_base + lr - 2, c_base + lc - 2);
+    s_psi[lr][lc] = nb.psi;
+    s_qx[lr][lc] = nb.qx;
+    s_qy[lr][lc] = nb.qy;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    int tr = tr0 + k * RPP;
+    // opaque per node: otherwise the 18 store addresses of the later nodes are derived from the first node's and wait
+    // in registers (scratch at 128) through its collision
+    asm volatile("" : "+v"(tr));
+    // likewise the wave-uniform f64 products of the source term (c_q . Fg: VALU work, there is no scalar f64 unit) are
+    // recomputed per node instead of waiting in ten register pairs
+    CgFast cfk = cf;
+    asm volatile("" : "+s"(cfk.Gr), "+s"(cfk.Gc));
+    double fk[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) fk[q] = (PARK && k > 0) ? s_park[k > 0 ? k - 1 : 0][q][threadIdx.x] : ft[PARK ? 0 : k][q];
+    CgNode me;  // == cg_node's expressions on the held sums
+    me.rr = rr[k];
+    me.rb = rb[k];
+    const double jx = ((fk[1] - fk[3]) + (fk[5] - fk[6])) + (fk[8] - fk[7]);
+    const double jy = ((fk[2] - fk[4]) + (fk[5] - fk[8])) + (fk[6] - fk[7]);
+    me.irt = 1.0 / (me.rr + me.rb);
+    me.ux = (jx + 0.5 * cfk.Gr) * me.irt;
+    me.uy = (jy + 0.5 * cfk.Gc) * me.irt;
+    me.psi = s_psi[tr + 2][tc + 2];
+    me.qx = me.qy = 0.0;  // not used by the collision
+    const double gx = cg_ddrow<LDC>(s_psi, tr, tc), gy = cg_ddcol<LDC>(s_psi, tr, tc);
+    const double dxqx = cg_ddrow<LDC>(s_qx, tr, tc), dyqy = cg_ddcol<LDC>(s_qy, tr, tc);
+    cg_collide_store<WITH_FIELDS>(fk, me, gx, gy, dxqx, dyqy, cfk, g, mi, r_base + tr, c_base + tc, pn_r, pn_b,
+                                  rho_r_out, rho_b_out, u_out, psi_out, snu_out);
+    if (k + 1 < NPT) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 #ifdef LBM_EXPERIMENTS  // the launch forms below (merged dispatch, strip kernels 1 - 4) were measured and not kept: make EXPERIMENTS=1
 // frame tiles and inner tiles in ONE dispatch: workgroups [0, n_frame) run the frame instantiation (general boundary
 // gather), the rest the inner one (plain offsets).  The two-launch form either runs the frame behind the inner launch

@@ -23,5 +23,8 @@ int ipc_sendrecv(IpcTransport* t, const double* send_prev, size_t n_send_prev, d
                  const double* send_next, size_t n_send_next, double* recv_next, size_t n_recv_next, hipStream_t st);
 // 0, or the code of the first wait that gave up (a neighbour that never delivered): 1 = data, 2 = acknowledgement
 int ipc_status(const IpcTransport* t);
+// 1 if the receive window lives in ordinary (cached) device memory because the uncached allocation was refused and the
+// caller had allowed that ("ring_ipc_cached_ok")
+int ipc_window_cached(const IpcTransport* t);
 
 }  // namespace lbm

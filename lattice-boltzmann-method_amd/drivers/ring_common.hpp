@@ -116,6 +116,15 @@ inline void share_unique_id(unsigned char (&id)[128], int rank, int world, const
     wait_file(id_file, id, sizeof id);
   }
 }
+// after the timed launches (and their sync): a rank whose ring has given up on a neighbour -- a bounded wait of the
+// peer-mapped transport, an asynchronous RCCL error -- has void lattices and void timings: it says so as JSON and the
+// driver returns 4 instead of printing a rate (its peers are ended by the launcher)
+inline int ring_failed(lbm_ring* ring, const char* driver, int rank) {
+  if (lbm_ring_status(ring) == 0) return 0;
+  std::printf("{\"driver\": \"%s\", \"rank\": %d, \"error\": \"%s\"}\n", driver, rank, lbm_last_error_string());
+  std::fflush(stdout);
+  return 4;
+}
 // slowest rank's time, gathered on rank 0 through files
 inline double max_time_over_ranks(double sec, int rank, int world, const std::string& id_file) {
   double tmax = sec;

@@ -10,6 +10,7 @@
 //          ghost rows = P x D; default 2) --edge-rows E --omega w
 //          --model bgk|kbc (kbc: the entropic KBC collision with s2 = omega, config 3 over slabs)
 //          --check 1 (N ranks vs rank 0 recomputing the whole box: small sizes only)
+//          --desert R (fault injection: rank R joins the ring and leaves; the others must report it and return 4)
 //
 // The block binding this generalises: test/decompose_domain.cpp:181-187 (3 populations per
 // interface row, one row per step); here 9(D-1) rows per side per D-step launch (3 for D = 1).
@@ -50,7 +51,7 @@ void init_node(double* f9, int gr, int c, int Rg, int C) {
 }
 
 struct Args {
-  int rows = 8192, cols = 8192, steps = 20, warmup = 5, depth = 5, period = 2, edge_rows = 32, check = 0;
+  int rows = 8192, cols = 8192, steps = 20, warmup = 5, depth = 5, period = 2, edge_rows = 32, check = 0, desert = -1;
   double omega = 1.2;
   bool kbc = false;
   std::string id_file;
@@ -104,6 +105,10 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   }
   lbm_ring* ring = nullptr;
   check(lbm_ring_create(&ring, id, rank, world, &g, /*periodic=*/1), "lbm_ring_create");
+  if (rank == a.desert) {  // joined, mapped, gone
+    std::fflush(nullptr);
+    _exit(0);
+  }
 
   const size_t plane = (size_t)(R + 2 * G) * C;
   double* lat[2];
@@ -126,6 +131,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   for (int i = 0; i < a.steps; ++i) launch();
   check(lbm_stream_sync(nullptr), "sync");
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (const int failed = ring_failed(ring, "slab_ring_box", rank)) return failed;
 
   // gather the per-rank times through files (no MPI here); value = all nodes / slowest rank
   double tmax = sec;
@@ -205,6 +211,7 @@ int main(int argc, char** argv) {
   a.period = std::max(1, std::min(3, std::atoi(arg_value(argc, argv, "--period", "2").c_str())));
   a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "32").c_str());
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
+  a.desert = std::atoi(arg_value(argc, argv, "--desert", "-1").c_str());
   a.omega = std::atof(arg_value(argc, argv, "--omega", "1.2").c_str());
   a.kbc = arg_value(argc, argv, "--model", "bgk") == "kbc";
   if (a.kbc && a.depth > 4) a.depth = 3;

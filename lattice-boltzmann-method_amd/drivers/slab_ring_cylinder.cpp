@@ -181,6 +181,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   for (int i = 0; i < nb; ++i) block();
   check(lbm_stream_sync(nullptr), "sync");
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (const int failed = ring_failed(ring, "slab_ring_cylinder", rank)) return failed;
   const double tmax = max_time_over_ranks(sec, rank, world, a.id_file);
   double Fs[2] = {0, 0};
   if (owner) {

@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-ORACLE_SO = os.path.join(_HERE, "_build", "liblbm_oracle.so")
+ORACLE_SO = os.environ.get("LBM_ORACLE_LIB", os.path.join(_HERE, "_build", "liblbm_oracle.so"))  # (the sanitizer build: make san)
 REF_SO = os.path.join(_HERE, "_ref", "libref_lbm.so")
 REF_DIR = os.path.join(_HERE, "_ref")
 

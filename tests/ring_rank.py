@@ -45,6 +45,7 @@ def main():
         ring = ct.c_void_p()
         lib.ring_create_ex(ct.byref(ring), ident, rank, n, ct.byref(geom), int(periodic), transport)
         assert lib.raw.lbm_ring_transport(ring) == transport
+        assert lib.raw.lbm_ring_window_cached(ring) == int(cfg.get("expect_cached", 0))
         return ring
 
     def zeros(R, G, C):
@@ -67,10 +68,13 @@ def main():
         lib.ring_join(ring, None)
         step = lib.ring_bgk_step if case == "bgk" else lib.ring_kbc_step
         cur = 0
+        import time
+        t0 = time.time()
         for depth in cfg["depths"]:
             step(ring, _ptr(lat[cur ^ 1]), _ptr(lat[cur]), ct.byref(bc), ct.byref(prm), int(depth), cfg.get("edge_rows", 16), None)
             cur ^= 1
         torch.cuda.synchronize()
+        open(os.path.join(work, f"drain_{rank}.txt"), "w").write(repr(time.time() - t0))   # how long the queue took to drain
         lib.ring_status(ring)
         out["P"] = lat[cur][:, G:G + R].cpu().numpy()
         lib.ring_destroy(ring)

@@ -310,13 +310,17 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         cases = [(0, 64), (0, 0),                                      # tile kernel split / unsplit
                  (51, 40), (51, 16), (52, 9), (52, 64), (52, 24),      # 51 / 52: the walking block (cg_strip2 = 41 / 42: 4 x 1, 6 x 1 waves)
                  (53, 40), (54, 33), (55, 64), (56, 40), (56, 7), (57, 40), (57, 9),  # ... 2 x 2, 3 x 2, 2 x 3, 2 x 1, 3 x 1 waves
-                 (61, 40), (61, 16)]                                   # 61: 4 x 1 without prefetch (cg_walk_pf = 0), 4 waves per SIMD
+                 (61, 40), (61, 16),                                   # 61: 4 x 1 without prefetch (cg_walk_pf = 0), 4 waves per SIMD
+                 (101, 64), (102, 64), (103, 64), (104, 64),           # 100 + s: several nodes per thread (cg_big = s), k_cg_tile_mn
+                 (105, 64), (106, 64), (107, 64), (108, 64)]
         if lib.raw.lbm_build_has_experiments():                       # the strip kernels, generations 1 - 5 (make EXPERIMENTS=1)
             cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33),
                       (21, 40), (22, 9),                               # 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
                       (31, 40), (31, 7), (32, 9), (32, 64),            # 31 / 32: the lockstep block kernel (cg_strip2 = 21 / 22)
                       (41, 40), (42, 9), (42, 64), (42, 33)]           # 41 / 42: adjacent strips kept loosely together (cg_strip2 = 31 / 32)
         for strip, rows in cases:
+            big, strip = (strip - 100, 0) if strip > 100 else (0, strip)
+            lib.set_tuning(b"cg_big", big)
             lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
             lib.set_tuning(b"cg_strip2", 41 if strip == 61 else (strip - 10 if strip >= 10 else 0))
             lib.set_tuning(b"cg_walk_pf", 0 if strip == 61 else -1)
@@ -329,11 +333,14 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                                   ct.byref(pg), 0, R, None, None, None, None, None, None)
                 a, b = b, a
             torch.cuda.synchronize()
-            res[(strip, rows)] = a
-            if strip >= 50 or strip == 0:   # the opt-in form really ran where the lattice has an inner rectangle
+            res[(strip + 100 * big, rows)] = a
+            if big:   # the big tiles really ran where the inner rectangle holds one (every shape fits 224 x 160)
+                assert lib.raw.lbm_cg_last_inner_form() in ((100 + big,) if (R, C) == (256, 200) else (0, 100 + big))
+            elif strip >= 50 or strip == 0:   # the opt-in form really ran where the lattice has an inner rectangle
                 want = (41 if strip == 61 else strip - 10) if (strip and rows and C >= 100) else 0
                 assert lib.raw.lbm_cg_last_inner_form() == want, (strip, rows, lib.raw.lbm_cg_last_inner_form())
     finally:
+        lib.set_tuning(b"cg_big", -1)
         lib.set_tuning(b"cg_strip", -1)
         lib.set_tuning(b"cg_strip2", -1)
         lib.set_tuning(b"cg_walk_pf", -1)

@@ -295,3 +295,35 @@ def test_a_rank_that_never_arrives_is_reported_not_waited_for_forever(lib, tmp_p
     with pytest.raises(AssertionError, match="never delivered"):
         run_ranks(lib, tmp_path, "bgk", 2, dict(R=R, C=C, ghost=5, depths=[5], bc=hexof(bc), prm=hexof(prm),
                                                 desert=1, tuning=dict(ring_ipc_timeout_ms=1500)), dict(p0=p0))
+
+
+def test_a_queue_of_launches_behind_a_deserter_drains_in_one_time_limit(lib, tmp_path):
+    """the failure of a bounded wait is sticky (capi_ring_ipc.hip): eight queued launch-steps (each with up to four waits)
+    behind a neighbour that left take ONE time limit to drain, not 32 of them"""
+    R, C = 64, 128
+    f0 = perturbed_rest(2 * R, C, seed=1)
+    bc, prm = pylbm.Bc(), pylbm.BgkParams(1.2, 0)
+    p0, _ = box_reference(lib, "bgk", f0, bc, prm, 0)
+    with pytest.raises(AssertionError, match="never delivered"):
+        run_ranks(lib, tmp_path, "bgk", 2, dict(R=R, C=C, ghost=5, depths=[5] * 8, bc=hexof(bc), prm=hexof(prm),
+                                                desert=1, tuning=dict(ring_ipc_timeout_ms=1500)), dict(p0=p0))
+    drain = float(open(os.path.join(str(tmp_path), "drain_0.txt")).read())
+    assert 1.0 < drain < 4.0, drain
+
+
+def test_refused_uncached_window_fails_unless_accepted(lib, tmp_path):
+    """the receive window is allocated uncached; a refusal (forced here by "ring_ipc_force_cached") fails the creation with
+    a sentence, and with "ring_ipc_cached_ok" the ring runs on a cached window, says so and is still bitwise right"""
+    R, C = 64, 128
+    f0 = perturbed_rest(2 * R, C, seed=2)
+    bc, prm = pylbm.Bc(), pylbm.BgkParams(1.2, 0)
+    p0, want = box_reference(lib, "bgk", f0, bc, prm, 10)
+    cfg = dict(R=R, C=C, ghost=5, depths=[5, 5], bc=hexof(bc), prm=hexof(prm))
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    with pytest.raises(AssertionError, match="uncached allocation of the receive window was refused"):
+        run_ranks(lib, tmp_path / "a", "bgk", 2, dict(cfg, tuning=dict(ring_ipc_force_cached=1)), dict(p0=p0))
+    outs = run_ranks(lib, tmp_path / "b", "bgk", 2, dict(cfg, expect_cached=1, tuning=dict(ring_ipc_force_cached=1, ring_ipc_cached_ok=1)),
+                     dict(p0=p0))
+    got = np.concatenate([o["P"] for o in outs], axis=1)
+    assert bits_equal(got, want)

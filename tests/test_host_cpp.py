@@ -11,12 +11,13 @@ import tomli
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "lattice-boltzmann-method_amd")
-DUMP = os.path.join(PKG, "drivers", "bin", "params_dump")
+DUMP = os.environ.get("LBM_PARAMS_DUMP", os.path.join(PKG, "drivers", "bin", "params_dump"))   # (the sanitizer build: make san)
 
 
 @pytest.fixture(scope="module")
 def dump():
-    subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "drivers"), "bin/params_dump"])
+    if "LBM_PARAMS_DUMP" not in os.environ:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(PKG, "drivers"), "bin/params_dump"])
     return DUMP
 
 
