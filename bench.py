@@ -745,7 +745,9 @@ class Secondary:
             self.step = lambda n: self.sv.step(n)
         elif which == "cg":     # config 4: mrtcg_rayleigh_taylor.cpp:182-210 (init_rho_cosine) at 8192 x 2048
             R, C = 8192, 2048
-            self.unit, self.kernel = 1, "k_cg_fused<16,32,4> (inner rectangle) + its frame instantiation"
+            self.unit = 1
+            self.kernel = ("k_cg_tile_mn<16,64,512,4,parked> (inner rectangle: 16x64 tiles, 2 nodes per thread, patches of 8x2 tiles per XCD) "
+                           "+ k_cg_fused<16,32,4,.,2> on the frame")
             self.bytes_per_update, self.config = 288.0, "mrtcg_rayleigh_taylor 8192x2048 colour-gradient two-phase MRT, gamma3 parameters"
             prm = pylbm.cg_params()
             rr = np.arange(R).reshape(-1, 1)
@@ -763,7 +765,7 @@ class Secondary:
         elif which == "ibm":    # config 5: cylinder_test.cpp:88-164, diameter 300 at rows / 4
             R, C = 16384, 4096
             self.unit = int(lib.raw.lbm_get_tuning(b"ibm_depth")) or 5
-            self.kernel = "k_stream_collide_sw_walls<BgkModelT<0,1>,5,nt> (rows away from the cylinder) + forced box chain"
+            self.kernel = "k_stream_collide_sw<BgkFastModel,5,2,nt> + wall frame (rows away from the cylinder) beside the forced box chain"
             self.bytes_per_update, self.config = 144.0, "cylinder_test 16384x4096 BGK + immersed cylinder (d = 300, 942 markers), one block"
             omega, u_in = 1.0 / 0.55, 0.04
             m = int(round(np.pi * 300))
@@ -838,11 +840,11 @@ def run_secondary(lib, dev, which, a):
             w.step(n)
             torch.cuda.synchronize()
         power = power_probe(_some, 1.0)
-    # informative second figure of config 4 (as `reference_order` is for the headline): the same steps through the opt-in
-    # walking-block kernel, which reads each plane row once per strip -- same bits, fewer bytes, its own clock
+    # informative second figure of config 4 (as `reference_order` is for the headline): the same steps through round 3's
+    # default, the 16 x 32 tile kernel with one node per thread (tuning cg_big = 0) -- same bits, more bytes
     opt_in = None
-    if which == "cg" and not any(kv.startswith("cg_strip2=") for kv in a.tune):
-        lib.set_tuning(b"cg_strip2", 41)
+    if which == "cg" and not any(kv.startswith("cg_big=") for kv in a.tune):
+        lib.set_tuning(b"cg_big", 0)
         try:
             w.step(n)
             torch.cuda.synchronize()
@@ -852,12 +854,12 @@ def run_secondary(lib, dev, which, a):
                 w.step(n)
                 torch.cuda.synchronize()
                 ws.append(time.perf_counter() - t0)
-            opt_in = {"kernel": "k_cg_walk<4,1> (tuning cg_strip2 = 41) on the inner rectangle + the tile kernel's frame instantiation",
+            opt_in = {"kernel": "k_cg_fused<16,32,4> (tuning cg_big = 0: the default of rounds 1-3) on the inner rectangle + its frame instantiation",
                       "value": round(w.R * w.C * n / sorted(ws)[1] / 1e6, 1), "unit": "MLUPS", "steps": n, "repeats": 3,
                       "note": "bit-identical to the default kernel (tests/test_gpu_cg.py, tests/test_gpu_fullsize.py)"}
             if not a.no_pmc:
                 try:
-                    pm = pmc_between_markers(which, ["--tune", "cg_strip2=41"] + [x for kv in a.tune for x in ("--tune", kv)])
+                    pm = pmc_between_markers(which, ["--tune", "cg_big=0"] + [x for kv in a.tune for x in ("--tune", kv)])
                     g_ = PMC_GROUPS[which]
                     fe = 2.0 * 1024.0 * sum(v[0] for v in pm["FETCH_SIZE"].values()) / g_
                     wr = 1024.0 * sum(v[0] for v in pm["WRITE_SIZE"].values()) / g_
@@ -866,12 +868,13 @@ def run_secondary(lib, dev, which, a):
                 except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
                     opt_in["traffic_source"] = f"PMC passes failed: {type(e).__name__}: {e}"
         finally:
-            lib.set_tuning(b"cg_strip2", -1)
+            lib.set_tuning(b"cg_big", -1)
     w.close()
-    # config 5's second figure: the same block with the collision reassociated (tuning bgk_fast_delta = 1: what the
-    # headline runs by default) -- 1e-10 against the oracle instead of bitwise (tests/test_gpu_ibm.py)
+    # config 5's second figure: the same block with the collision in the reference's operation order (parameters' form =
+    # LBM_FORM_REFERENCE_ORDER) -- BITWISE equal to the oracle (tests/test_gpu_ibm.py, tests/test_gpu_fullsize.py); the
+    # default since round 4 is the reassociated collision, as for every other model (1e-10 against the oracle)
     if which == "ibm" and not any(kv.startswith("bgk_fast_delta=") for kv in a.tune):
-        lib.set_tuning(b"bgk_fast_delta", 1)
+        lib.set_tuning(b"bgk_fast_delta", 0)
         try:
             w2 = Secondary(lib, dev, which)
             w2.step(n)
@@ -883,10 +886,11 @@ def run_secondary(lib, dev, which, a):
                 torch.cuda.synchronize()
                 ws.append(time.perf_counter() - t0)
             w2.close()
-            opt_in = {"kernel": "the same block, far rows through k_stream_collide_sw<BgkFastModel,5,2,nt> (tuning bgk_fast_delta = 1)",
+            opt_in = {"kernel": "the same block in the reference's operation order: far rows through k_stream_collide_sw<BgkModelT<0,1>,5,2,nt> "
+                                "(LBM_FORM_REFERENCE_ORDER / tuning bgk_fast_delta = 0)",
                       "value": round(w.R * w.C * n / sorted(ws)[1] / 1e6, 1), "unit": "MLUPS", "steps": n, "repeats": 3,
-                      "note": "reassociated collision: 1e-10 relative against the oracle after 13 steps instead of bitwise "
-                              "(tests/test_gpu_ibm.py::test_cylinder_with_reassociated_delta_form)"}
+                      "note": "bitwise equal to the CPU oracle (tests/test_gpu_fullsize.py::test_config5_fullsize_ibm_block_vs_oracle); "
+                              "the default (reassociated) collision: 1e-10 relative after 13 steps (tests/test_gpu_ibm.py)"}
         finally:
             lib.set_tuning(b"bgk_fast_delta", -1)
     mid = sorted(range(5), key=lambda i: wall[i])[2]

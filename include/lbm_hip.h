@@ -54,6 +54,7 @@ int lbm_stream_sync(lbm_stream_t s);
 int lbm_event_create(void** ev);
 int lbm_event_destroy(void* ev);
 int lbm_event_record(void* ev, lbm_stream_t s);
+int lbm_stream_wait_event(lbm_stream_t s, void* ev); /* work enqueued on s afterwards waits for ev (hipStreamWaitEvent) */
 int lbm_event_elapsed_ms(float* ms, void* start, void* stop); /* synchronises on stop */
 
 /* ---- HIP graphs: capture a launch sequence of this library once, replay it per step -----------------
@@ -313,6 +314,17 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
                       const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int row_begin,
                       int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* s_nu,
                       lbm_stream_t s);
+/* the same step as TWO launches for a slab whose neighbours wait for its edge rows: LBM_CG_PART_FRAME = the boundary-gather
+ * instantiation on the frame of the lattice widened to the first and last `edge_rows` rows (whole tiles of 16 rows),
+ * LBM_CG_PART_INNER = everything else through the plain-offset inner kernel.  The parts write disjoint nodes and may run
+ * on two streams at once (lbm_ring_cg_step: frame, pack and exchange on the ring's stream beside the inner launch);
+ * together they are lbm_cg_step_fused on [0, R), bit for bit (test/mrtcg_rayleigh_taylor.cpp:431-477 per node). */
+#define LBM_CG_PART_FRAME 1
+#define LBM_CG_PART_INNER 2
+int lbm_cg_step_fused_part(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                           const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int part,
+                           int edge_rows, double* rho_r, double* rho_b, double* u, double* psi, double* s_nu,
+                           lbm_stream_t s);
 /* which kernel the calling thread's last lbm_cg_step_fused launched for the INNER rectangle of the lattice: 0 the LDS tile
  * kernel (default), 41..47 the walking block (tuning "cg_strip2"), other values the strip kernels of an
  * EXPERIMENTS build; -1 before the first call.  An opt-in form the geometry does not admit falls back to the tile kernel --

@@ -83,7 +83,10 @@ template <int TR, int TC, int WAVES>
 static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, const double* in_b,
                              const Geom& g, const Bc& bc, const CgFast& cf, double* rho_r,
                              double* rho_b, double* u, double* psi, double* snu, const MacroIdx& mi,
-                             int row_begin, int row_end, hipStream_t st) {
+                             int row_begin, int row_end, hipStream_t st, int part = 0, int edge_rows = 0) {
+  // part 0: the whole row range (frame beside the inner launch on a helper stream); 1 / 2: ONLY the frame -- widened to the
+  // first and last `edge_rows` rows of the range, in whole tiles -- / ONLY the inner rectangle, on `st`: a slab runs the
+  // two on two streams and sends its edge rows while the inner launch is still busy (lbm_cg_step_fused_part)
   const int tiles_r = (row_end - row_begin + TR - 1) / TR, tiles_c = (g.C + TC - 1) / TC;
   const int tiles = tiles_r * tiles_c;
   const int xs = tuning("cg_xcd", 2);  // pairs of column-neighbour tiles per XCD: +5 % at 4 waves per SIMD
@@ -102,16 +105,29 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   }
   rc.ic1 = (g.C - 3) / TC;  // last tile column with c_base + TC + 1 <= C - 2
   if (rc.ic1 > tiles_c) rc.ic1 = tiles_c;
-  bool split = tuning("cg_split", 1) != 0 && rc.ir1 - rc.ir0 >= 1 && rc.ic1 - rc.ic0 >= 1;
+  if (part && edge_rows > 0) {
+    const int et = (edge_rows + TR - 1) / TR;
+    rc.ir0 = rc.ir0 > et ? rc.ir0 : et;
+    rc.ir1 = rc.ir1 < tiles_r - et ? rc.ir1 : tiles_r - et;
+  }
+  bool split = (part || tuning("cg_split", 1) != 0) && rc.ir1 - rc.ir0 >= 1 && rc.ic1 - rc.ic0 >= 1;
   g_last_inner_form = 0;
   // several nodes per thread (k_cg_tile_mn): the inner rectangle is cut into BIG tiles from its top-left corner, what does
   // not fill a big tile joins the frame.  100 + shape; shapes: {rows, columns, threads, waves per SIMD the registers are budgeted for}
-  const int big = TR == 16 && TC == 32 ? tuning("cg_big", 0) : 0;
+  // default (round 4): 16 x 64 tiles, two nodes per thread, the waiting one parked in LDS -- +4 .. +7 % over the 16 x 32 tile
+  // kernel on every box measured (profiles/r04_cg_big_sweep.txt); "cg_big" = 0 restores k_cg_fused<16,32,4> on the inner rectangle
+  const int big = TR == 16 && TC == 32 ? tuning("cg_big", 2) : 0;
   static const int big_shapes[][4] = {{32, 32, 512, 4}, {16, 64, 512, 4}, {16, 128, 1024, 4}, {32, 64, 1024, 4},
-                                      {32, 64, 512, 2}, {8, 64, 512, 4}, {16, 64, 1024, 4}, {16, 128, 512, 2}};
+                                      {32, 64, 512, 2}, {8, 64, 512, 4}, {16, 64, 1024, 4}, {16, 128, 512, 2},
+                                      {16, 32, 512, 4}};
   int n_btr = 0, n_btc = 0;
-  if (split && big >= 1 && big <= (int)(sizeof big_shapes / sizeof big_shapes[0])) {
-    const int* s = big_shapes[big - 1];
+#ifndef LBM_EXPERIMENTS
+  const int shape = big > 0 ? 2 : 0;  // the default build ships shape 2 only (any non-zero "cg_big" selects it)
+#else
+  const int shape = big >= 1 && big <= (int)(sizeof big_shapes / sizeof big_shapes[0]) ? big : 0;
+#endif
+  if (split && shape) {
+    const int* s = big_shapes[shape - 1];
     const int rows16 = ((rc.ir1 - rc.ir0) * 16 / s[0]) * s[0] / 16 * 16;  // rows the big tiles cover: whole big tiles AND whole 16-row units
     n_btr = rows16 / s[0];
     n_btc = (rc.ic1 - rc.ic0) * 32 / s[1];
@@ -121,6 +137,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     } else n_btr = n_btc = 0;
   }
   if (!split) {
+    if (part == 2) return LBM_OK;  // no inner rectangle: the frame part runs every tile
     if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
     else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false>), dim3(tiles), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs);
     LBM_CHECK_LAUNCH();
@@ -128,7 +145,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   }
   const int inner = (rc.ir1 - rc.ir0) * (rc.ic1 - rc.ic0), frame = tiles - inner;
 #ifdef LBM_EXPERIMENTS
-  if (frame > 0 && !tuning("cg_strip2", 0) && tuning("cg_merge", 0)) {  // frame + inner tiles in one dispatch (opt-in: measured level with the two-launch form, 15.24 k either way)
+  if (!part && frame > 0 && !tuning("cg_strip2", 0) && tuning("cg_merge", 0)) {  // frame + inner tiles in one dispatch (opt-in: measured level with the two-launch form, 15.24 k either way)
     if (psi) LBM_KLAUNCH((k_cg_fused_merged<TR, TC, WAVES, true>), dim3(frame + inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc, frame);
     else LBM_KLAUNCH((k_cg_fused_merged<TR, TC, WAVES, false>), dim3(frame + inner), dim3(TR * TC), 0, st, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, xs, rc, frame);
     LBM_CHECK_LAUNCH();
@@ -137,31 +154,37 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
 #endif
   // the frame (3-4 % of the tiles, latency-bound: 63 us on its own) goes FIRST and on the helper stream, so
   // that it runs beside the inner launch instead of behind it (fork / join through two events, launch.hpp)
-  SwSideStream* sd = frame > 0 && tuning("cg_frame_beside", 1) ? sw_side_stream() : nullptr;
+  SwSideStream* sd = !part && frame > 0 && tuning("cg_frame_beside", 1) ? sw_side_stream() : nullptr;
   hipStream_t fs = st;
   if (sd && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->st, sd->fork, 0) == hipSuccess) fs = sd->st;
-  if (frame > 0) {
+  if (frame > 0 && part != 2) {
     if (psi) LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, true, 2>), dim3(frame), dim3(TR * TC), 0, fs, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
     else LBM_KLAUNCH((k_cg_fused<TR, TC, WAVES, false, 2>), dim3(frame), dim3(TR * TC), 0, fs, pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, 0, rc);
     LBM_CHECK_LAUNCH();
   }
+  if (part == 1) return LBM_OK;
   const int sw4 = n_btr ? 0 : tuning("cg_strip2", 0);
   if (n_btr) {  // k_cg_tile_mn: big tiles, several nodes per thread
     const int ra = row_begin + rc.ir0 * TR, ca = rc.ic0 * TC, nt = n_btr * n_btc;
-    const int bx = tuning("cg_big_xcd", 2);
-    g_last_inner_form = 100 + big;
+    // patches of 8 x 2 tiles per XCD (100 PR + PC): ring rows and ring columns inside a patch are hits of one L2 (2: pairs of
+    // column neighbours as k_cg_fused; the tall patches add 3 - 4 % on top, profiles/r04_cg_big_sweep.txt)
+    const int bx = tuning("cg_big_xcd", 802);
+    g_last_inner_form = 100 + shape;
 #define LBM_CG_BIG(BR, BC, BT, BM, BP)                                                                               \
     if (psi) LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, true>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx); \
     else LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, false>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx);
-    switch (big) {
+    switch (shape) {
+#ifdef LBM_EXPERIMENTS  // the shapes of the round-4 sweep that lost to 16 x 64 (profiles/r04_cg_big_sweep.txt)
       case 1: LBM_CG_BIG(32, 32, 512, 4, true) break;    // 2 nodes per thread, the second parked in LDS: 2 workgroups per CU
-      case 2: LBM_CG_BIG(16, 64, 512, 4, true) break;
       case 3: LBM_CG_BIG(16, 128, 1024, 4, true) break;  // 1024 threads: one workgroup per CU
       case 4: LBM_CG_BIG(32, 64, 1024, 4, true) break;
       case 5: LBM_CG_BIG(32, 64, 512, 2, false) break;   // 4 nodes per thread, 2 waves per SIMD: one workgroup per CU
       case 6: LBM_CG_BIG(8, 64, 512, 4, false) break;    // one node per thread in the wide shape (what the width alone is worth)
       case 7: LBM_CG_BIG(16, 64, 1024, 4, false) break;
-      default: LBM_CG_BIG(16, 128, 512, 2, false) break;
+      case 8: LBM_CG_BIG(16, 128, 512, 2, false) break;
+      case 9: LBM_CG_BIG(16, 32, 512, 4, false) break;   // the default tile's shape, one node per thread: what the patch orders alone are worth
+#endif
+      default: LBM_CG_BIG(16, 64, 512, 4, true) break;   // shape 2: 16 x 64, 2 nodes per thread, the second parked in LDS
     }
 #undef LBM_CG_BIG
   } else
@@ -383,10 +406,10 @@ int lbm_cg_stream_collide(double* pn_r, double* pn_b, const double* p_r, const d
   return launch_cg_collide(true, pn_r, pn_b, p_r, p_b, rho_r, rho_b, u, g, bc, prm, psi, snu, row_begin, row_end, as_stream(s));
 }
 
-int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
-                      const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int row_begin,
-                      int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* snu,
-                      lbm_stream_t s) {
+static int cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                         const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int row_begin,
+                         int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* snu,
+                         lbm_stream_t s, int part, int edge_rows) {
   int rc = check_cg("lbm_cg_step_fused", g, bc, prm);
   if (rc) return rc;
   LBM_REQUIRE(pn_r && pn_b && p_r && p_b, "lbm_cg_step_fused: NULL lattice");
@@ -415,8 +438,25 @@ int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const doubl
     case 1: return launch_cg_fused_t<16, 32, 1>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 5: return launch_cg_fused_t<32, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 6: return launch_cg_fused_t<16, 64, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
-    default: return launch_cg_fused_t<16, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
+    default: return launch_cg_fused_t<16, 32, 4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st, part, edge_rows);
   }
+}
+
+int lbm_cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                      const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int row_begin,
+                      int row_end, double* rho_r, double* rho_b, double* u, double* psi, double* snu,
+                      lbm_stream_t s) {
+  return cg_step_fused(pn_r, pn_b, p_r, p_b, g, bc, prm, row_begin, row_end, rho_r, rho_b, u, psi, snu, s, 0, 0);
+}
+
+int lbm_cg_step_fused_part(double* pn_r, double* pn_b, const double* p_r, const double* p_b,
+                           const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int part,
+                           int edge_rows, double* rho_r, double* rho_b, double* u, double* psi, double* snu,
+                           lbm_stream_t s) {
+  LBM_REQUIRE(part == LBM_CG_PART_FRAME || part == LBM_CG_PART_INNER, "lbm_cg_step_fused_part: part=%d (LBM_CG_PART_FRAME / _INNER)", part);
+  LBM_REQUIRE(g && edge_rows >= 0 && 2 * edge_rows <= g->R, "lbm_cg_step_fused_part: edge_rows=%d", edge_rows);
+  LBM_REQUIRE(tuning("cg_tile", 4) == 4, "lbm_cg_step_fused_part: needs the default tile kernel (\"cg_tile\" = 4)");
+  return cg_step_fused(pn_r, pn_b, p_r, p_b, g, bc, prm, 0, g->R, rho_r, rho_b, u, psi, snu, s, part, edge_rows);
 }
 
 }  // extern "C"

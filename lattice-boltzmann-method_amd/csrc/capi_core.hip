@@ -433,6 +433,11 @@ int lbm_event_record(void* ev, lbm_stream_t s) {
   LBM_CHECK_HIP(hipEventRecord((hipEvent_t)ev, as_stream(s)));
   return LBM_OK;
 }
+int lbm_stream_wait_event(lbm_stream_t s, void* ev) {
+  LBM_REQUIRE(ev, "lbm_stream_wait_event: NULL event");
+  LBM_CHECK_HIP(hipStreamWaitEvent(as_stream(s), (hipEvent_t)ev, 0));
+  return LBM_OK;
+}
 int lbm_event_elapsed_ms(float* ms, void* start, void* stop) {
   LBM_REQUIRE(ms, "lbm_event_elapsed_ms: NULL out pointer");
   LBM_CHECK_HIP(hipEventSynchronize((hipEvent_t)stop));

@@ -368,9 +368,19 @@ int lbm_ring_cg_step(lbm_ring* rg, double* dst_r, double* dst_b, const double* s
   LBM_CHECK_HIP(hipStreamWaitEvent(rg->edge, rg->main_done, 0));
   int rc = LBM_OK;
   if (rg->prev >= 0 || rg->next >= 0) {
-    rc = rows(0, edge_rows, rg->edge);
-    if (!rc) rc = rows(R - edge_rows, R, rg->edge);
-    if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
+    if (tuning("ring_cg_parts", 1) && tuning("cg_tile", 4) == 4 && tuning("cg_strip", 0) == 0) {
+      // round 4: TWO compute launches per step instead of three row ranges of two each -- the frame of the slab (its wall /
+      // copy columns AND the first and last edge rows, whose results the neighbours wait for) on the ring's stream with the
+      // exchange behind it, the inner rectangle on the caller's stream beside both
+      rc = lbm_cg_step_fused_part(dst_r, dst_b, src_r, src_b, &rg->g, &b, prm, LBM_CG_PART_FRAME, edge_rows, nullptr, nullptr, nullptr,
+                                  nullptr, nullptr, rg->edge);
+      if (!rc) rc = lbm_cg_step_fused_part(dst_r, dst_b, src_r, src_b, &rg->g, &b, prm, LBM_CG_PART_INNER, edge_rows, nullptr, nullptr,
+                                           nullptr, nullptr, nullptr, main);
+    } else {
+      rc = rows(0, edge_rows, rg->edge);
+      if (!rc) rc = rows(R - edge_rows, R, rg->edge);
+      if (!rc) rc = rows(edge_rows, R - edge_rows, main);  // interior overlaps the exchange
+    }
     if (!rc) rc = ring_exchange(rg, dst_r, dst_b, rg->edge);
   } else {
     rc = rows(0, R, main);

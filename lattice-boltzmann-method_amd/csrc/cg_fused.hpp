@@ -420,15 +420,51 @@ __global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
   __shared__ double s_psi[LR][LDC], s_qx[LR][LDC], s_qy[LR][LDC];
   __shared__ double s_park[PARK ? NPT - 1 : 1][PARK ? Q : 1][PARK ? NT : 1];
   int tile = blockIdx.x;
-  if (xcd_swizzle > 1) {  // groups of G column-neighbour tiles per XCD inside a common window (as k_cg_fused)
-    const int G = xcd_swizzle, x = tile % 8, m = tile / 8, win = 8 * G;
-    const int t2 = (m / G) * win + x * G + (m % G);
-    if ((m / G + 1) * win <= (int)gridDim.x) tile = t2;
-  } else if (xcd_swizzle == 1) {
-    const int per = gridDim.x / 8;
-    if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+  int tile_r, tile_c;
+  if (xcd_swizzle >= 100) {
+    // PATCHES: consecutive workgroups of one XCD (b % 8 = the XCD, b / 8 = its m-th workgroup) take the PR x PC tiles of one
+    // patch, so that both the ring rows and the ring columns inside a patch are hits of that XCD's L2; the eight XCDs work on
+    // eight neighbouring patches.  What does not fill a group of eight whole patches follows in plain order.
+    const int PR = xcd_swizzle / 100, PC = xcd_swizzle % 100, P = PR * PC;
+    const int tiles_r = gridDim.x / tiles_c, pr_n = tiles_r / PR, pc_n = tiles_c / PC;
+    const int covered = (pr_n * pc_n / 8) * 8;  // whole patches in groups of eight
+    if (tile < covered * P) {
+      const int x = tile % 8, m = tile / 8, gp = (m / P) * 8 + x, j = m % P;
+      tile_r = (gp / pc_n) * PR + j / PC;
+      tile_c = (gp % pc_n) * PC + j % PC;
+    } else {
+      int k = tile - covered * P;
+      const int left = pr_n * pc_n - covered;  // whole patches beyond the last group of eight
+      if (k < left * P) {
+        const int gp = covered + k / P, j = k % P;
+        tile_r = (gp / pc_n) * PR + j / PC;
+        tile_c = (gp % pc_n) * PC + j % PC;
+      } else {
+        k -= left * P;
+        const int wr = tiles_c - pc_n * PC;  // tile columns right of the patches
+        if (k < pr_n * PR * wr) {
+          tile_r = k / wr;
+          tile_c = pc_n * PC + k % wr;
+        } else {
+          k -= pr_n * PR * wr;
+          tile_r = pr_n * PR + k / tiles_c;
+          tile_c = k % tiles_c;
+        }
+      }
+    }
+  } else {
+    if (xcd_swizzle > 1) {  // groups of G column-neighbour tiles per XCD inside a common window (as k_cg_fused)
+      const int G = xcd_swizzle, x = tile % 8, m = tile / 8, win = 8 * G;
+      const int t2 = (m / G) * win + x * G + (m % G);
+      if ((m / G + 1) * win <= (int)gridDim.x) tile = t2;
+    } else if (xcd_swizzle == 1) {
+      const int per = gridDim.x / 8;
+      if (tile < per * 8) tile = (tile % 8) * per + tile / 8;
+    }
+    tile_r = tile / tiles_c;
+    tile_c = tile % tiles_c;
   }
-  const int r_base = ra + (tile / tiles_c) * TR, c_base = ca + (tile % tiles_c) * TC;
+  const int r_base = ra + tile_r * TR, c_base = ca + tile_c * TC;
   const int tr0 = threadIdx.x / TC, tc = threadIdx.x % TC;
 
   double ft[PARK ? 1 : NPT][Q], rr[NPT], rb[NPT];
@@ -501,590 +537,9 @@ __global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
   }
 }
 
-#ifdef LBM_EXPERIMENTS  // the launch forms below (merged dispatch, strip kernels 1 - 4) were measured and not kept: make EXPERIMENTS=1
-// frame tiles and inner tiles in ONE dispatch: workgroups [0, n_frame) run the frame instantiation (general boundary
-// gather), the rest the inner one (plain offsets).  The two-launch form either runs the frame behind the inner launch
-// (63 us) or beside it on a helper stream, whose event fork / join costs as much as it hides (profiles/r02_ring_dissect.txt).
-template <int TR, int TC, int WAVES, bool WITH_FIELDS>
-__global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused_merged(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int xcd_swizzle, CgTileRect rect,
-    int n_frame) {
-  if ((int)blockIdx.x < n_frame)
-    cg_fused_body<TR, TC, WITH_FIELDS, 2>(pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r_out, rho_b_out, u_out, psi_out, snu_out, mi,
-                                          row_begin, row_end, 0, rect, (int)blockIdx.x, n_frame);
-  else
-    cg_fused_body<TR, TC, WITH_FIELDS, 1>(pn_r, pn_b, in_r, in_b, g, bc, cf, rho_r_out, rho_b_out, u_out, psi_out, snu_out, mi,
-                                          row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x - n_frame, (int)gridDim.x - n_frame);
-}
-
-// ---- column-strip sliding window --------------------------------------------------------------
-// One WAVEFRONT owns a strip of 64 columns (60 outputs + the +-2 stencil ring) and walks down a
-// chunk of rows.  Every iteration it (1) streams one new row of both colours and reduces it to
-// psi, Qx, Qy, which go into a wave-private LDS ring of the last 5 rows; (2) collides the row two
-// behind: its own 18 populations are gathered again (L2 / L1 hits: the wave read them two
-// iterations ago) and the 5x5 stencils read the ring.  Rows are wave-uniform, so the gathers are
-// scalar-base + lane-offset loads; nothing is recomputed along r (4 warm-up rows per chunk), only
-// 4 of 64 columns along c; no workgroup barrier exists (LDS visibility inside a wave needs only
-// program order).  Against the tile kernel above: ~2x less HBM read traffic (its +-3 column ring
-// costs whole 128-B lines on both sides of a 32-column tile, 299 B read per node measured).
-// Same per-node arithmetic as the tile kernel: identical bits.
-// MEASURED (8192 x 2048): 11.5 k MLUPS (4 waves per block, 16 rows per chunk) against the tile
-// kernel's 14.1 k -- opt-in (tuning "cg_strip" = 1 / 2 / 4 waves per block, "cg_rows").  History: 6.3 k
-// with two inlined copies of the gather and the stencils unrolled (362 VGPRs, 1 wave per SIMD);
-// one inlined copy (a 2-pass loop) and rolled stencil loops: 166 VGPRs, 3 waves per SIMD.  What
-// still separates it from the tile kernel: the row to collide is gathered a second time (its
-// populations are not kept across the two iterations) and nothing is prefetched.
-constexpr int CG_SW = 60;  // output columns per wavefront
-
-template <int WAVES, bool WITH_FIELDS>
-__global__ __launch_bounds__(64 * WAVES) void k_cg_strip(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, Bc bc, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int rows_per_chunk,
-    int strips, int n_waves) {
-#pragma clang fp contract(on)
-  __shared__ double ring[WAVES][3][5][64 + 4];  // [wave][field][slot][2 pad + lane + 2 pad]
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * WAVES + wib;
-  if (wave >= n_waves) return;
-  const int strip = wave % strips, chunk = wave / strips;
-  const int R0 = row_begin + chunk * rows_per_chunk;
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int rlo = cg_row_lo(g, bc), rhi = cg_row_hi(g, bc);
-  const int c = strip * CG_SW - 2 + lane;                   // this lane's column (may be outside)
-  const int cm = c < 0 ? 0 : (c > g.C - 1 ? g.C - 1 : c);   // replicate padding along c
-  const bool lane_out = lane >= 2 && lane < 2 + CG_SW && c < g.C;
-  // strips that touch column 0 / C-1 need the boundary gather (the same-row column copy, Q5)
-  const bool edge_strip = strip * CG_SW - 3 <= 0 || strip * CG_SW + CG_SW + 2 >= g.C - 1;
-  double(*s_psi)[68] = ring[wib][0];
-  double(*s_qx)[68] = ring[wib][1];
-  double(*s_qy)[68] = ring[wib][2];
-
-  auto node = [&](double (&ft)[Q], int row, int col) -> CgNode {
-    // rows 0 / R-1 of the block carry wall fix-ups; (single block) their neighbours wrap
-    const bool plain = !edge_strip && row >= 1 && row <= g.R - 2;
-    if (!plain) return cg_node<false>(ft, in_r, in_b, g, bc, cf, row, col);
-    double fr[Q];
-    const long ro[3] = {g.at(row + 1, 0), g.at(row, 0), g.at(row - 1, 0)};  // source rows of cx = -1, 0, +1
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long o = q * g.plane + ro[icx(q) + 1] + (col - icy(q));
-      fr[q] = in_r[o];
-      ft[q] = in_b[o];
-    }
-    CgNode n;
-    n.rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
-    n.rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] += fr[q];
-    const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
-    const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
-    n.irt = 1.0 / (n.rr + n.rb);
-    n.ux = (jx + 0.5 * cf.Gr) * n.irt;
-    n.uy = (jy + 0.5 * cf.Gc) * n.irt;
-    const double a = n.rr * cf.inv_rho0[0], b = n.rb * cf.inv_rho0[1];
-    n.psi = (a - b) / (a + b);
-    const double qcs = cf.qc[0] * n.rr + cf.qc[1] * n.rb;
-    n.qx = qcs * n.ux;
-    n.qy = qcs * n.uy;
-    return n;
-  };
-
-  const int n_iter = (R1 - R0) + 4;
-  for (int i = 0; i < n_iter; ++i) {
-    // two gathers per iteration through ONE inlined copy of `node`: pass 0 = the new macroscopic
-    // row R0 - 2 + i (-> ring slot i % 5), pass 1 = the row to collide, r = R0 + i - 4
-    double ft[Q];
-    CgNode me;
-    const int r = R0 + i - 4;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-      int row, col;
-      if (pass == 0) {
-        row = R0 - 2 + i;
-        row = row < rlo ? rlo : (row > rhi ? rhi : row);  // replicate padding along r (global edges only)
-        col = cm;
-      } else {
-        if (i < 4) break;
-        row = r;
-        col = lane_out ? c : cm;
-      }
-      me = node(ft, row, col);
-      if (pass == 0) {
-        const int slot = i % 5;
-        s_psi[slot][lane + 2] = me.psi;
-        s_qx[slot][lane + 2] = me.qx;
-        s_qy[slot][lane + 2] = me.qy;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    if (i < 4) continue;
-    if (lane_out) {
-      // the 5 ring rows in stencil order; columns lane-2 .. lane+2 sit at [lane .. lane+4]
-      const int s0 = (i - 4) % 5, s1 = (i - 3) % 5, s3 = (i - 1) % 5, s4 = i % 5;
-      constexpr double k = 1.0 / 5040.0;
-      constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-      constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
-      double gx = 0.0, dxqx = 0.0;
-#pragma unroll 1
-      for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-        gx += a0[j] * (s_psi[s4][lane + j] - s_psi[s0][lane + j]);
-        gx += a1[j] * (s_psi[s3][lane + j] - s_psi[s1][lane + j]);
-        dxqx += a0[j] * (s_qx[s4][lane + j] - s_qx[s0][lane + j]);
-        dxqx += a1[j] * (s_qx[s3][lane + j] - s_qx[s1][lane + j]);
-      }
-      double gy = 0.0, dyqy = 0.0;
-#pragma unroll 1
-      for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
-        const int sl = (i - 4 + ii) % 5;
-        gy += a0[ii] * (s_psi[sl][lane + 4] - s_psi[sl][lane]);
-        gy += a1[ii] * (s_psi[sl][lane + 3] - s_psi[sl][lane + 1]);
-        dyqy += a0[ii] * (s_qy[sl][lane + 4] - s_qy[sl][lane]);
-        dyqy += a1[ii] * (s_qy[sl][lane + 3] - s_qy[sl][lane + 1]);
-      }
-      cg_collide_store<WITH_FIELDS>(ft, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out,
-                                    rho_b_out, u_out, psi_out, snu_out);
-    }
-    // the slot written next iteration is (i + 1) % 5 = the oldest row, no longer read: no hazard
-  }
-}
-
-
-// ---- column-strip sliding window, second generation: the INNER rectangle of a launch ------------------
-// As k_cg_strip, with what separated it from the tile kernel removed:
-//   * the colour-summed populations and macroscopic fields of a row are KEPT in registers (a ring of 3
-//     rows, the row loop unrolled by 3 so that every index is static) from the iteration that streams
-//     the row to the one, two later, that collides it -- nothing is gathered twice;
-//   * the 18 loads of the next row are issued before the current row is reduced and collided;
-//   * it only ever runs on nodes whose +-2 ring and +-1 gathers are plain (the inner rectangle the tile
-//     launch already separates from its frame): no clamps, no wraps, no boundary gather;
-//   * 56 output columns per wave (lanes 4..59; lanes 2, 3, 60, 61 carry the stencil ring): every row a
-//     wave stores starts on a 64-byte boundary.
-// Every lattice row of the rectangle is read once per strip (64 of 56 columns) plus 4 warm-up rows per
-// chunk; the frame keeps the tile kernel.  Per-node arithmetic = the tile kernel's: identical bits.
-constexpr int CG_SW2 = 56;
-
-template <int K, bool WITH_FIELDS>
-__device__ __forceinline__ void cg_strip2_iter(
-    double (&rf)[3][Q], double (&rn)[3][6], double (&raw_r)[3][Q], double (&raw_b)[3][Q], double (*s_psi)[68],
-    double (*s_qx)[68], double (*s_qy)[68], double* __restrict__ pn_r, double* __restrict__ pn_b,
-    const double* __restrict__ in_r, const double* __restrict__ in_b, const Geom& g, const CgFast& cf,
-    const MacroIdx& mi, int i, int n_iter, int R0, int lane, int cl, int c, bool lane_out,
-    double* __restrict__ rho_r_out, double* __restrict__ rho_b_out, double* __restrict__ u_out,
-    double* __restrict__ psi_out, double* __restrict__ snu_out) {
-#pragma clang fp contract(on)
-  if (i >= n_iter) return;  // wave-uniform
-  // raw populations of this iteration's macroscopic row R0 - 2 + i arrived in buffer K; the buffer the
-  // previous iteration consumed ((K + 2) % 3) takes the row TWO ahead: two rows of loads stay in flight
-  constexpr int KN = (K + 2) % 3;
-  if (i + 2 < n_iter) {
-    const long o = g.at(R0 + i, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[KN][q] = in_r[off];
-      raw_b[KN][q] = in_b[off];
-    }
-  }
-  double ft[Q];
-  const double (&fr)[Q] = raw_r[K];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) ft[q] = raw_b[K][q];
-  // reduce the arrived row (== cg_node<true>)
-  const double rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
-  const double rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) ft[q] += fr[q];
-  const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
-  const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
-  const double irt = 1.0 / (rr + rb);
-  const double ux = (jx + 0.5 * cf.Gr) * irt, uy = (jy + 0.5 * cf.Gc) * irt;
-  const double a = rr * cf.inv_rho0[0], b = rb * cf.inv_rho0[1];
-  const double psi = (a - b) / (a + b);
-  const double qcs = cf.qc[0] * rr + cf.qc[1] * rb;
-  const int slot = i % 5;
-  s_psi[slot][lane + 2] = psi;
-  s_qx[slot][lane + 2] = qcs * ux;
-  s_qy[slot][lane + 2] = qcs * uy;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) rf[K][q] = ft[q];
-  rn[K][0] = rr; rn[K][1] = rb; rn[K][2] = ux; rn[K][3] = uy; rn[K][4] = irt; rn[K][5] = psi;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (i < 4 || !lane_out) return;
-  // collide row r = R0 + i - 4: reduced two iterations ago (ring slot K + 1 mod 3)
-  constexpr int KC = (K + 1) % 3;
-  const int r = R0 + i - 4;
-  const int s0 = (i - 4) % 5, s1 = (i - 3) % 5, s3 = (i - 1) % 5, s4 = i % 5;
-  constexpr double k = 1.0 / 5040.0;
-  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
-  // one wave per SIMD and registers to spare: the 80 ring reads of the four stencils are issued together
-  // (unrolled), the accumulation order stays that of cg_ddrow / cg_ddcol
-  double gx = 0.0, dxqx = 0.0;
-#pragma unroll
-  for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-    gx += a0[j] * (s_psi[s4][lane + j] - s_psi[s0][lane + j]);
-    gx += a1[j] * (s_psi[s3][lane + j] - s_psi[s1][lane + j]);
-    dxqx += a0[j] * (s_qx[s4][lane + j] - s_qx[s0][lane + j]);
-    dxqx += a1[j] * (s_qx[s3][lane + j] - s_qx[s1][lane + j]);
-  }
-  double gy = 0.0, dyqy = 0.0;
-#pragma unroll
-  for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
-    const int sl = (i - 4 + ii) % 5;
-    gy += a0[ii] * (s_psi[sl][lane + 4] - s_psi[sl][lane]);
-    gy += a1[ii] * (s_psi[sl][lane + 3] - s_psi[sl][lane + 1]);
-    dyqy += a0[ii] * (s_qy[sl][lane + 4] - s_qy[sl][lane]);
-    dyqy += a1[ii] * (s_qy[sl][lane + 3] - s_qy[sl][lane + 1]);
-  }
-  double fc[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) fc[q] = rf[KC][q];
-  CgNode me;
-  me.rr = rn[KC][0]; me.rb = rn[KC][1]; me.ux = rn[KC][2]; me.uy = rn[KC][3]; me.irt = rn[KC][4]; me.psi = rn[KC][5];
-  me.qx = 0.0; me.qy = 0.0;
-  cg_collide_store<WITH_FIELDS>(fc, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out, rho_b_out,
-                                u_out, psi_out, snu_out);
-}
-
-// one wave per SIMD (~350 VGPRs): budgeted for two, the kernel spilled 16 registers into scratch memory and
-// lost more to their reloads (12.7 k MLUPS) than the second wave hid
-template <int WAVES, bool WITH_FIELDS>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_cg_strip2(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
-    int rows_per_chunk, int strips, int n_waves) {
-  __shared__ double ring[WAVES][3][5][68];  // [wave][field][slot][2 pad + lane + 2 pad]
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int wave = blockIdx.x * WAVES + wib;
-  if (wave >= n_waves) return;
-  const int strip = wave % strips, chunk = wave / strips;
-  const int R0 = row_begin + chunk * rows_per_chunk;
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int c = col_begin + strip * CG_SW2 - 4 + lane;  // this lane's column
-  const bool lane_out = lane >= 4 && lane < 4 + CG_SW2 && c < col_end;
-  // loads stay inside the rectangle's ring (its +-1 gathers are in bounds by construction)
-  const int cl = c < col_begin - 2 ? col_begin - 2 : (c > col_end + 1 ? col_end + 1 : c);
-  double(*s_psi)[68] = ring[wib][0];
-  double(*s_qx)[68] = ring[wib][1];
-  double(*s_qy)[68] = ring[wib][2];
-  double rf[3][Q], rn[3][6], raw_r[3][Q], raw_b[3][Q];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) rf[a][q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rn[a][q] = 1.0;
-  }
-  const int n_iter = (R1 - R0) + 4;
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {  // the first two macroscopic rows: R0 - 2, R0 - 1 (n_iter >= 5)
-    const long o = g.at(R0 - 2 + a, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[a][q] = in_r[off];
-      raw_b[a][q] = in_b[off];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < Q; ++q) raw_r[2][q] = raw_b[2][q] = 0.0;
-  for (int i = 0; i < n_iter; i += 3) {
-    cg_strip2_iter<0, WITH_FIELDS>(rf, rn, raw_r, raw_b, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i, n_iter, R0, lane, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    cg_strip2_iter<1, WITH_FIELDS>(rf, rn, raw_r, raw_b, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 1, n_iter, R0, lane, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    cg_strip2_iter<2, WITH_FIELDS>(rf, rn, raw_r, raw_b, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 2, n_iter, R0, lane, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-  }
-}
-
-
-// ---- third generation: two waves per SIMD -----------------------------------------------------------------
-// k_cg_strip2 needs ~390 registers (one wave per SIMD: every dependent chain of the collision is exposed).
-// Here the colour-summed populations of the 3 ring rows wait in wave-private LDS instead (13.8 KB per wave;
-// the six macroscopic values per row stay in registers), and the raw populations of the next row are loaded
-// into the registers the reduction has just freed: ~210 VGPRs, two waves per SIMD, 22 KB of LDS per wave.
-template <int K, bool WITH_FIELDS>
-__device__ __forceinline__ void cg_strip3_iter(
-    double (&rn)[3][6], double (&raw_r)[Q], double (&raw_b)[Q], double (*s_ft)[Q][64], double (*s_psi)[68],
-    double (*s_qx)[68], double (*s_qy)[68], double* __restrict__ pn_r, double* __restrict__ pn_b,
-    const double* __restrict__ in_r, const double* __restrict__ in_b, const Geom& g, const CgFast& cf,
-    const MacroIdx& mi, int i, int n_iter, int R0, int lane, int cl, int c, bool lane_out,
-    double* __restrict__ rho_r_out, double* __restrict__ rho_b_out, double* __restrict__ u_out,
-    double* __restrict__ psi_out, double* __restrict__ snu_out) {
-#pragma clang fp contract(on)
-  if (i >= n_iter) return;  // wave-uniform
-  {
-    // reduce the arrived row R0 - 2 + i (== cg_node<true>)
-    const double (&fr)[Q] = raw_r;
-    double ft[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] = raw_b[q];
-    const double rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
-    const double rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] += fr[q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) s_ft[K][q][lane] = ft[q];
-    const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
-    const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
-    const double irt = 1.0 / (rr + rb);
-    const double ux = (jx + 0.5 * cf.Gr) * irt, uy = (jy + 0.5 * cf.Gc) * irt;
-    const double a = rr * cf.inv_rho0[0], b = rb * cf.inv_rho0[1];
-    const double psi = (a - b) / (a + b);
-    const double qcs = cf.qc[0] * rr + cf.qc[1] * rb;
-    const int slot = i % 5;
-    s_psi[slot][lane + 2] = psi;
-    s_qx[slot][lane + 2] = qcs * ux;
-    s_qy[slot][lane + 2] = qcs * uy;
-    rn[K][0] = rr; rn[K][1] = rb; rn[K][2] = ux; rn[K][3] = uy; rn[K][4] = irt; rn[K][5] = psi;
-  }
-  if (i + 1 < n_iter) {  // the next row into the registers just freed; in flight during the collision below
-    const long o = g.at(R0 - 1 + i, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (i < 4 || !lane_out) return;
-  constexpr int KC = (K + 1) % 3;
-  const int r = R0 + i - 4;
-  const int s0 = (i - 4) % 5, s1 = (i - 3) % 5, s3 = (i - 1) % 5, s4 = i % 5;
-  constexpr double k = 1.0 / 5040.0;
-  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
-  double gx = 0.0, dxqx = 0.0;
-#pragma unroll 1
-  for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-    gx += a0[j] * (s_psi[s4][lane + j] - s_psi[s0][lane + j]);
-    gx += a1[j] * (s_psi[s3][lane + j] - s_psi[s1][lane + j]);
-    dxqx += a0[j] * (s_qx[s4][lane + j] - s_qx[s0][lane + j]);
-    dxqx += a1[j] * (s_qx[s3][lane + j] - s_qx[s1][lane + j]);
-  }
-  double gy = 0.0, dyqy = 0.0;
-#pragma unroll 1
-  for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
-    const int sl = (i - 4 + ii) % 5;
-    gy += a0[ii] * (s_psi[sl][lane + 4] - s_psi[sl][lane]);
-    gy += a1[ii] * (s_psi[sl][lane + 3] - s_psi[sl][lane + 1]);
-    dyqy += a0[ii] * (s_qy[sl][lane + 4] - s_qy[sl][lane]);
-    dyqy += a1[ii] * (s_qy[sl][lane + 3] - s_qy[sl][lane + 1]);
-  }
-  double fc[Q];
-#pragma unroll
-  for (int q = 0; q < Q; ++q) fc[q] = s_ft[KC][q][lane];
-  CgNode me;
-  me.rr = rn[KC][0]; me.rb = rn[KC][1]; me.ux = rn[KC][2]; me.uy = rn[KC][3]; me.irt = rn[KC][4]; me.psi = rn[KC][5];
-  me.qx = 0.0; me.qy = 0.0;
-  cg_collide_store<WITH_FIELDS>(fc, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out, rho_b_out,
-                                u_out, psi_out, snu_out);
-}
-
-template <int WAVES, bool WITH_FIELDS>
-__global__ __launch_bounds__(64 * WAVES, 2) void k_cg_strip3(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
-    int rows_per_chunk, int strips, int n_waves, int xcd_order) {
-  __shared__ double ring[WAVES][3][5][68];  // [wave][field][slot][2 pad + lane + 2 pad]
-  __shared__ double ftr[WAVES][3][Q][64];   // [wave][ring row][population][lane]
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  // workgroups are dealt round-robin over the 8 XCDs: with xcd_order, XCD k takes the k-th contiguous eighth of
-  // the (chunk-major, strip-minor) sequence, so that neighbouring strips -- which share the 128-byte lines at
-  // their window edges -- run back to back on one L2 instead of on eight different ones
-  int blk = blockIdx.x;
-  if (xcd_order) blk = (blk % 8) * ((int)gridDim.x / 8) + blk / 8;  // the launch pads the grid to a multiple of 8
-  const int wave = blk * WAVES + wib;
-  if (wave >= n_waves) return;
-  const int strip = wave % strips, chunk = wave / strips;
-  const int R0 = row_begin + chunk * rows_per_chunk;
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int c = col_begin + strip * CG_SW2 - 4 + lane;
-  const bool lane_out = lane >= 4 && lane < 4 + CG_SW2 && c < col_end;
-  const int cl = c < col_begin - 2 ? col_begin - 2 : (c > col_end + 1 ? col_end + 1 : c);
-  double(*s_psi)[68] = ring[wib][0];
-  double(*s_qx)[68] = ring[wib][1];
-  double(*s_qy)[68] = ring[wib][2];
-  double(*s_ft)[Q][64] = ftr[wib];
-  double rn[3][6], raw_r[Q], raw_b[Q];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rn[a][q] = 1.0;
-  {
-    const long o = g.at(R0 - 2, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  const int n_iter = (R1 - R0) + 4;
-  for (int i = 0; i < n_iter; i += 3) {
-    cg_strip3_iter<0, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i, n_iter, R0, lane, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    cg_strip3_iter<1, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 1, n_iter, R0, lane, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    cg_strip3_iter<2, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 2, n_iter, R0, lane, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-  }
-}
-
-// ---- fourth generation: a WORKGROUP of W waves walks down a 64 W-column window in lockstep ------------------------
-// What the round-3 calibration (scripts/calib/fetch_calib.hip, profiles/r03_fetch_calib.txt) showed: the L2 fetches whole
-// 128-BYTE LINES, one request per line a wave's load touches, and neighbouring waves share a line only when they sit in
-// one workgroup at the same time.  A private 64-column window with 56 outputs that starts 32 bytes off a line boundary
-// (k_cg_strip2 / 3) therefore pays 5 lines for 3.5 lines of output on every one of its 18 streams -- the 1.38x read
-// amplification PMC measured.  Here
-//   * the block's window starts on a line boundary (a multiple of 16 columns) and is 64 W columns wide; only its first and
-//     last 8 lanes are ring-only, so a block reads 4 W lines per row and stream for 4 W - 1 lines of output (W = 4: 1.067x),
-//     and the +-1-column pulls of a wave land in lines its neighbours in the block load in the same iteration;
-//   * psi, Qx, Qy of a row go into ONE ring shared by the block (6 slots: the slot a fast wave writes next is never one a
-//     slow wave still reads), so all lanes but the 16 at the block's edges produce output -- one workgroup barrier per row;
-//   * the colour-summed populations wait in a wave-private ring of TWO rows (the row just reduced stays in registers until
-//     the row two behind it has been collided out of the slot it takes): 18.4 KB of LDS per wave, 8 waves per CU.
-// Per-node arithmetic = the tile kernel's: identical bits.
-constexpr int CG_S4_EDGE = 8;
-
-template <int W, int K, bool WITH_FIELDS>
-__device__ __forceinline__ void cg_strip4_iter(
-    double (&rn)[3][6], double (&raw_r)[Q], double (&raw_b)[Q], double (*s_ft)[Q][64], double (*s_psi)[64 * W],
-    double (*s_qx)[64 * W], double (*s_qy)[64 * W], double* __restrict__ pn_r, double* __restrict__ pn_b,
-    const double* __restrict__ in_r, const double* __restrict__ in_b, const Geom& g, const CgFast& cf,
-    const MacroIdx& mi, int i, int n_iter, int R0, int lane, int gl, int cl, int c, bool lane_out,
-    double* __restrict__ rho_r_out, double* __restrict__ rho_b_out, double* __restrict__ u_out,
-    double* __restrict__ psi_out, double* __restrict__ snu_out) {
-#pragma clang fp contract(on)
-  if (i >= n_iter) return;  // uniform over the block: all its waves walk the same chunk
-  double ft[Q];
-  {
-    // reduce the arrived row R0 - 2 + i (== cg_node<true>)
-    const double (&fr)[Q] = raw_r;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] = raw_b[q];
-    const double rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
-    const double rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] += fr[q];
-    const double jx = ((ft[1] - ft[3]) + (ft[5] - ft[6])) + (ft[8] - ft[7]);
-    const double jy = ((ft[2] - ft[4]) + (ft[5] - ft[8])) + (ft[6] - ft[7]);
-    const double irt = 1.0 / (rr + rb);
-    const double ux = (jx + 0.5 * cf.Gr) * irt, uy = (jy + 0.5 * cf.Gc) * irt;
-    const double a = rr * cf.inv_rho0[0], b = rb * cf.inv_rho0[1];
-    const double psi = (a - b) / (a + b);
-    const double qcs = cf.qc[0] * rr + cf.qc[1] * rb;
-    const int slot = i % 6;
-    s_psi[slot][gl] = psi;
-    s_qx[slot][gl] = qcs * ux;
-    s_qy[slot][gl] = qcs * uy;
-    rn[K][0] = rr; rn[K][1] = rb; rn[K][2] = ux; rn[K][3] = uy; rn[K][4] = irt; rn[K][5] = psi;
-  }
-  if (i + 1 < n_iter) {  // the next row into the registers just freed; in flight during the collision below
-    const long o = g.at(R0 - 1 + i, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  __syncthreads();  // the row's psi, Qx, Qy of every wave of the block are in the ring
-  if (i >= 4 && lane_out) {
-    constexpr int KC = (K + 1) % 3;
-    const int r = R0 + i - 4;
-    const int s0 = (i - 4) % 6, s1 = (i - 3) % 6, s3 = (i - 1) % 6, s4 = i % 6;
-    constexpr double k = 1.0 / 5040.0;
-    constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-    constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
-    const int l0 = gl - 2;  // columns c - 2 .. c + 2 sit at [l0 .. l0 + 4]
-    double gx = 0.0, dxqx = 0.0;
-#pragma unroll 1
-    for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-      gx += a0[j] * (s_psi[s4][l0 + j] - s_psi[s0][l0 + j]);
-      gx += a1[j] * (s_psi[s3][l0 + j] - s_psi[s1][l0 + j]);
-      dxqx += a0[j] * (s_qx[s4][l0 + j] - s_qx[s0][l0 + j]);
-      dxqx += a1[j] * (s_qx[s3][l0 + j] - s_qx[s1][l0 + j]);
-    }
-    double gy = 0.0, dyqy = 0.0;
-#pragma unroll 1
-    for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
-      const int sl = (i - 4 + ii) % 6;
-      gy += a0[ii] * (s_psi[sl][l0 + 4] - s_psi[sl][l0]);
-      gy += a1[ii] * (s_psi[sl][l0 + 3] - s_psi[sl][l0 + 1]);
-      dyqy += a0[ii] * (s_qy[sl][l0 + 4] - s_qy[sl][l0]);
-      dyqy += a1[ii] * (s_qy[sl][l0 + 3] - s_qy[sl][l0 + 1]);
-    }
-    double fc[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) fc[q] = s_ft[i & 1][q][lane];  // reduced two iterations ago
-    CgNode me;
-    me.rr = rn[KC][0]; me.rb = rn[KC][1]; me.ux = rn[KC][2]; me.uy = rn[KC][3]; me.irt = rn[KC][4]; me.psi = rn[KC][5];
-    me.qx = 0.0; me.qy = 0.0;
-    cg_collide_store<WITH_FIELDS>(fc, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out, rho_b_out,
-                                  u_out, psi_out, snu_out);
-  }
-  // ... and only now does this iteration's row take that slot (same wave, same lanes: program order suffices)
-#pragma unroll
-  for (int q = 0; q < Q; ++q) s_ft[i & 1][q][lane] = ft[q];
-}
-
-template <int W, bool WITH_FIELDS>
-__global__ __launch_bounds__(64 * W, 2) void k_cg_strip4(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
-    int rows_per_chunk, int bstrips, int win0) {
-  __shared__ double ring[3][6][64 * W];  // [field][slot][block lane]
-  __shared__ double ftr[W][2][Q][64];    // [wave][ring row][population][lane]
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, gl = threadIdx.x;
-  constexpr int S = 64 * W - 2 * CG_S4_EDGE;  // output columns per block (a multiple of 16: windows stay line-aligned)
-  const int bs = blockIdx.x % bstrips, chunk = blockIdx.x / bstrips;
-  const int R0 = row_begin + chunk * rows_per_chunk;
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int c = win0 + bs * S + gl;  // this lane's column
-  const bool lane_out = gl >= CG_S4_EDGE && gl < 64 * W - CG_S4_EDGE && c >= col_begin && c < col_end;
-  // loads stay inside the lattice (lanes beyond the rectangle's ring feed nothing that is stored)
-  const int cl = c < 1 ? 1 : (c > g.C - 2 ? g.C - 2 : c);
-  double(*s_psi)[64 * W] = ring[0];
-  double(*s_qx)[64 * W] = ring[1];
-  double(*s_qy)[64 * W] = ring[2];
-  double(*s_ft)[Q][64] = ftr[wib];
-  double rn[3][6], raw_r[Q], raw_b[Q];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rn[a][q] = 1.0;
-  {
-    const long o = g.at(R0 - 2, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  const int n_iter = (R1 - R0) + 4;
-  for (int i = 0; i < n_iter; i += 3) {
-    cg_strip4_iter<W, 0, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i, n_iter, R0, lane, gl, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    cg_strip4_iter<W, 1, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 1, n_iter, R0, lane, gl, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    cg_strip4_iter<W, 2, WITH_FIELDS>(rn, raw_r, raw_b, s_ft, s_psi, s_qx, s_qy, pn_r, pn_b, in_r, in_b, g, cf, mi, i + 2, n_iter, R0, lane, gl, cl, c, lane_out, rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-  }
-}
-
-#endif  // LBM_EXPERIMENTS (strip kernels, generations 1 - 4)
+#ifdef LBM_EXPERIMENTS  // two-phase step, merged frame + inner dispatch and the strip kernels of generations 1 - 4: csrc/experiments/cg_strips_1_4.hpp
+#include "experiments/cg_strips_1_4.hpp"
+#endif
 
 __device__ __forceinline__ void cg_reduce_row(const double (&fr)[Q], double (&ft)[Q], const CgFast& cf, double (&n6)[6],
                                               double& psi, double& qx, double& qy) {
@@ -1106,114 +561,9 @@ __device__ __forceinline__ void cg_reduce_row(const double (&fr)[Q], double (&ft
   n6[0] = rr; n6[1] = rb; n6[2] = ux; n6[3] = uy; n6[4] = irt; n6[5] = psi;
 }
 
-#ifdef LBM_EXPERIMENTS  // 14.0-14.3 k against the tile kernel's 15.3 k
-// ---- fifth form: k_cg_strip3's private windows, FOUR adjacent strips per workgroup kept loosely together -------------------
-// The calibration of round 3 says neighbouring strips share a 128-byte line only inside one workgroup at about the same
-// time; k_cg_strip4 buys that with a shared ring and a barrier per row and loses more to the lockstep than it gains.  Here
-// every wave keeps its own 64-column window, rings and pace (no data passes between waves), the W waves of a workgroup own
-// ADJACENT strips of one chunk, and a workgroup barrier every `sync_every` rows only bounds how far they drift apart -- the
-// lines at the window edges are then mostly L2 hits.  Colour sums in a two-row ring (as k_cg_strip4): 17.4 KB of LDS per
-// wave, 8 waves per CU.  Per-node arithmetic = the tile kernel's: identical bits.
-template <int W, bool WITH_FIELDS>
-__global__ __launch_bounds__(64 * W, 2) void k_cg_strip5(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, CgFast cf, double* __restrict__ rho_r_out,
-    double* __restrict__ rho_b_out, double* __restrict__ u_out, double* __restrict__ psi_out,
-    double* __restrict__ snu_out, MacroIdx mi, int row_begin, int row_end, int col_begin, int col_end,
-    int rows_per_chunk, int groups, int sync_every) {
-#pragma clang fp contract(on)
-  __shared__ double ring[W][3][5][68];  // [wave][field][slot][2 pad + lane + 2 pad]
-  __shared__ double ftr[W][2][Q][64];   // [wave][ring row][population][lane]
-  const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int grp = blockIdx.x % groups, chunk = blockIdx.x / groups;
-  const int strip = grp * W + wib;
-  const int R0 = row_begin + chunk * rows_per_chunk;
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int c = col_begin + strip * CG_SW2 - 4 + lane;
-  const bool lane_out = lane >= 4 && lane < 4 + CG_SW2 && c < col_end;
-  const int cl = c < 1 ? 1 : (c > g.C - 2 ? g.C - 2 : c);
-  double(*s_psi)[68] = ring[wib][0];
-  double(*s_qx)[68] = ring[wib][1];
-  double(*s_qy)[68] = ring[wib][2];
-  double(*s_ft)[Q][64] = ftr[wib];
-  double rn[3][6], raw_r[Q], raw_b[Q];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rn[a][q] = 1.0;
-  {
-    const long o = g.at(R0 - 2, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  const int n_iter = (R1 - R0) + 4;
-  for (int i = 0; i < n_iter; ++i) {
-    if (sync_every > 0 && i % sync_every == 0) __syncthreads();  // uniform: all waves of a block walk the same chunk
-#pragma unroll
-    for (int q = 0; q < 6; ++q) rn[2][q] = rn[1][q], rn[1][q] = rn[0][q];
-    double ft[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] = raw_b[q];
-    double psi, qx, qy;
-    cg_reduce_row(raw_r, ft, cf, rn[0], psi, qx, qy);
-    const int slot = i % 5;
-    s_psi[slot][lane + 2] = psi;
-    s_qx[slot][lane + 2] = qx;
-    s_qy[slot][lane + 2] = qy;
-    if (i + 1 < n_iter) {
-      const long o = g.at(R0 - 1 + i, cl);
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-        raw_r[q] = in_r[off];
-        raw_b[q] = in_b[off];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (i >= 4 && lane_out) {
-      const int r = R0 + i - 4;
-      const int s0 = (i - 4) % 5, s1 = (i - 3) % 5, s3 = (i - 1) % 5, s4 = i % 5;
-      constexpr double k = 1.0 / 5040.0;
-      constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-      constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
-      double gx = 0.0, dxqx = 0.0;
-#pragma unroll 1
-      for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-        gx += a0[j] * (s_psi[s4][lane + j] - s_psi[s0][lane + j]);
-        gx += a1[j] * (s_psi[s3][lane + j] - s_psi[s1][lane + j]);
-        dxqx += a0[j] * (s_qx[s4][lane + j] - s_qx[s0][lane + j]);
-        dxqx += a1[j] * (s_qx[s3][lane + j] - s_qx[s1][lane + j]);
-      }
-      double gy = 0.0, dyqy = 0.0;
-#pragma unroll 1
-      for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
-        const int sl = (i - 4 + ii) % 5;
-        gy += a0[ii] * (s_psi[sl][lane + 4] - s_psi[sl][lane]);
-        gy += a1[ii] * (s_psi[sl][lane + 3] - s_psi[sl][lane + 1]);
-        dyqy += a0[ii] * (s_qy[sl][lane + 4] - s_qy[sl][lane]);
-        dyqy += a1[ii] * (s_qy[sl][lane + 3] - s_qy[sl][lane + 1]);
-      }
-      double fc[Q];
-#pragma unroll
-      for (int q = 0; q < Q; ++q) fc[q] = s_ft[i & 1][q][lane];  // reduced two iterations ago
-      CgNode me;
-      me.rr = rn[2][0]; me.rb = rn[2][1]; me.ux = rn[2][2]; me.uy = rn[2][3]; me.irt = rn[2][4]; me.psi = rn[2][5];
-      me.qx = 0.0; me.qy = 0.0;
-      cg_collide_store<WITH_FIELDS>(fc, me, gx, gy, dxqx, dyqy, cf, g, mi, r, c, pn_r, pn_b, rho_r_out, rho_b_out,
-                                    u_out, psi_out, snu_out);
-    }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) s_ft[i & 1][q][lane] = ft[q];
-  }
-}
-
-#endif  // LBM_EXPERIMENTS (fifth form)
+#ifdef LBM_EXPERIMENTS  // two-phase step, strip kernel of generation 5 (adjacent private windows): csrc/experiments/cg_strip5.hpp
+#include "experiments/cg_strip5.hpp"
+#endif
 
 // ---- sixth form: a workgroup of TR x WC waves walks down a strip, TR rows a step ---------------------------------------
 // Between the tile kernel (16 waves per CU, moves its actual traffic at 6.4-6.7 TB/s, but reduces 22 x 36 nodes for 16 x 32
@@ -1414,223 +764,8 @@ __global__ __launch_bounds__(TR* WC * 64, PF ? 3 : 4) void k_cg_walk(
   if (!stored) flush(R0 + (n_steps - 1) * TR, l_);
 }
 
-#ifdef LBM_EXPERIMENTS  // bit-identical to two single steps and SLOWER than them: make EXPERIMENTS=1
-// ---- TWO time steps per pass (round 3) -----------------------------------------------------------------
-// The k_cg_strip4 structure with a second level on top: a workgroup of W waves walks down a line-aligned 64 W-column window
-// in lockstep; level 1 is the single step of k_cg_strip4 (rows read from HBM, psi / Q in the block's ring 1), but its
-// post-collision populations (18 per node) go into LDS instead of HBM; level 2 pull-streams them -- the +-1-lane offset of
-// the ds_read IS the column shift, rows r-1, r, r+1 come from a compact ring (of a row published in iteration i the next
-// level reads the c_x = -1 populations in iteration i, the c_x = 0 ones in i + 1, the c_x = +1 ones in i + 2: 1 + 2 + 3
-// slots of 3 populations per colour) --, reduces them to the step-(t+1) macroscopic fields (ring 2), and collides the row
-// three behind, which is stored.  Per iteration: A level-1 reduce | barrier | C level-1 collide -> LDS | barrier | B level-2
-// pull + reduce, D level-2 collide -> HBM.  Every lattice row is read once and written once per TWO steps: 144 B per update
-// instead of 288.  One wave per SIMD (the colour sums and macroscopic values of 3 + 4 rows wait in registers), 141 KB of LDS
-// per 4-wave block.  Only for nodes whose two-step dependency cone holds plain nodes (launch_cg_two_steps: the frame of the
-// lattice advances two single steps on small band lattices).  Per-node arithmetic = two applications of the tile kernel's:
-// identical bits.
-constexpr int CG_X2_EDGE = 8;   // ring-only lanes at each end of a block's window (the two levels need 6)
-constexpr int CG_X2_WARM = 14;  // pipeline iterations before the first stored row
-
-template <int W>
-struct CgX2Lds {
-  double ring1[3][5][64 * W];    // [psi, Qx, Qy][slot][block lane]: step t+0 fields of the last 5 level-1 rows
-  double ring2[3][6][64 * W];    // the same for level 2 (6 slots: rows are consumed one iteration later than in level 1)
-  double p1[2][6][3][64 * W];    // [colour][slot: A | B0 B1 | C0 C1 C2][population of the group][block lane]
-};
-
-// the four 5x5 stencil results of the node at block lane l0 + 2 from a ring whose rows r-2 .. r+2 sit in slots sl[0..4]
-// (one wave per SIMD and registers to spare: the 80 ring reads are issued together; accumulation order of cg_ddrow / cg_ddcol)
-template <int LN, bool UNROLL>
-__device__ __forceinline__ void cg_stencils(const double (*s_psi)[LN], const double (*s_qx)[LN], const double (*s_qy)[LN],
-                                            const int (&sl)[5], int l0, double& gx, double& gy, double& dxqx, double& dyqy) {
-#pragma clang fp contract(on)
-  constexpr double k = 1.0 / 5040.0;
-  constexpr double a0[5] = {2 * k * 1, 2 * k * 32, 2 * k * 84, 2 * k * 32, 2 * k * 1};
-  constexpr double a1[5] = {k * 32, k * 448, k * 960, k * 448, k * 32};
-  gx = 0.0, dxqx = 0.0, gy = 0.0, dyqy = 0.0;
-  if constexpr (UNROLL) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {  // == cg_ddrow
-      gx += a0[j] * (s_psi[sl[4]][l0 + j] - s_psi[sl[0]][l0 + j]);
-      gx += a1[j] * (s_psi[sl[3]][l0 + j] - s_psi[sl[1]][l0 + j]);
-      dxqx += a0[j] * (s_qx[sl[4]][l0 + j] - s_qx[sl[0]][l0 + j]);
-      dxqx += a1[j] * (s_qx[sl[3]][l0 + j] - s_qx[sl[1]][l0 + j]);
-    }
-#pragma unroll
-    for (int ii = 0; ii < 5; ++ii) {  // == cg_ddcol
-      gy += a0[ii] * (s_psi[sl[ii]][l0 + 4] - s_psi[sl[ii]][l0]);
-      gy += a1[ii] * (s_psi[sl[ii]][l0 + 3] - s_psi[sl[ii]][l0 + 1]);
-      dyqy += a0[ii] * (s_qy[sl[ii]][l0 + 4] - s_qy[sl[ii]][l0]);
-      dyqy += a1[ii] * (s_qy[sl[ii]][l0 + 3] - s_qy[sl[ii]][l0 + 1]);
-    }
-  } else {
-#pragma unroll 1
-    for (int j = 0; j < 5; ++j) {
-      gx += a0[j] * (s_psi[sl[4]][l0 + j] - s_psi[sl[0]][l0 + j]);
-      gx += a1[j] * (s_psi[sl[3]][l0 + j] - s_psi[sl[1]][l0 + j]);
-      dxqx += a0[j] * (s_qx[sl[4]][l0 + j] - s_qx[sl[0]][l0 + j]);
-      dxqx += a1[j] * (s_qx[sl[3]][l0 + j] - s_qx[sl[1]][l0 + j]);
-    }
-#pragma unroll 1
-    for (int ii = 0; ii < 5; ++ii) {
-      gy += a0[ii] * (s_psi[sl[ii]][l0 + 4] - s_psi[sl[ii]][l0]);
-      gy += a1[ii] * (s_psi[sl[ii]][l0 + 3] - s_psi[sl[ii]][l0 + 1]);
-      dyqy += a0[ii] * (s_qy[sl[ii]][l0 + 4] - s_qy[sl[ii]][l0]);
-      dyqy += a1[ii] * (s_qy[sl[ii]][l0 + 3] - s_qy[sl[ii]][l0 + 1]);
-    }
-  }
-}
-
-// one pipeline iteration; STEADY: i >= CG_X2_WARM, so both collisions run unconditionally -- in ONE barrier interval, as
-// straight-line code the scheduler can interleave (at one wave per SIMD nothing else hides their dependent chains)
-template <int W, bool STEADY, int MODE>
-__device__ __forceinline__ void cg_two_step_iter(CgX2Lds<W>& L, double (&raw_r)[Q], double (&raw_b)[Q], double (&s1)[3][Q],
-                                                 double (&n1)[3][6], double (&s2)[3][Q], double (&n2)[3][6],
-                                                 double* __restrict__ pn_r, double* __restrict__ pn_b,
-                                                 const double* __restrict__ in_r, const double* __restrict__ in_b, const Geom& g,
-                                                 const CgFast& cf, int i, int n_iter, int R0, int gl, int l0, int cl, int c,
-                                                 bool lane_out) {
-#pragma clang fp contract(on)
-  constexpr int LN = 64 * W;
-  // ---- A: level-1 reduce of the arrived row m1 = R0 - 8 + i ----
-#pragma unroll
-  for (int q = 0; q < Q; ++q) s1[2][q] = s1[1][q], s1[1][q] = s1[0][q];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) n1[2][q] = n1[1][q], n1[1][q] = n1[0][q];
-  {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) s1[0][q] = raw_b[q];
-    double psi, qx, qy;
-    cg_reduce_row(raw_r, s1[0], cf, n1[0], psi, qx, qy);
-    const int slot = i % 5;
-    L.ring1[0][slot][gl] = psi;
-    L.ring1[1][slot][gl] = qx;
-    L.ring1[2][slot][gl] = qy;
-  }
-  if (i + 1 < n_iter) {  // the next row into the registers just freed; in flight during the collisions below
-    const long o = g.at(R0 - 7 + i, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  __syncthreads();
-  // ---- C: level-1 collision of row m1 - 2 (reduced two iterations ago); its populations of step t+1 into LDS ----
-  // ---- D: level-2 collision of row m2 - 3 = R0 - 14 + i (its ring rows were all published in earlier iterations) ----
-  double o_r[Q], o_b[Q], o2_r[Q], o2_b[Q], snu1, snu2;
-  if (STEADY || i >= 4) {
-    const int sl[5] = {(i - 4) % 5, (i - 3) % 5, (i - 2) % 5, (i - 1) % 5, i % 5};
-    double gx, gy, dxqx, dyqy;
-    cg_stencils<LN, (MODE & 1) != 0>(L.ring1[0], L.ring1[1], L.ring1[2], sl, l0, gx, gy, dxqx, dyqy);
-    CgNode me;
-    me.rr = n1[2][0]; me.rb = n1[2][1]; me.ux = n1[2][2]; me.uy = n1[2][3]; me.irt = n1[2][4]; me.psi = n1[2][5];
-    me.qx = 0.0; me.qy = 0.0;
-    cg_collide_values(s1[2], me, gx, gy, dxqx, dyqy, cf, o_r, o_b, snu1);
-  }
-  if (STEADY) {
-    const int sl[5] = {(i - 5) % 6, (i - 4) % 6, (i - 3) % 6, (i - 2) % 6, (i - 1) % 6};
-    double gx, gy, dxqx, dyqy;
-    cg_stencils<LN, (MODE & 2) != 0>(L.ring2[0], L.ring2[1], L.ring2[2], sl, l0, gx, gy, dxqx, dyqy);
-    CgNode me;
-    // (before this iteration's rotation of the level-2 rows: [2] = the row reduced three iterations ago)
-    me.rr = n2[2][0]; me.rb = n2[2][1]; me.ux = n2[2][2]; me.uy = n2[2][3]; me.irt = n2[2][4]; me.psi = n2[2][5];
-    me.qx = 0.0; me.qy = 0.0;
-    cg_collide_values(s2[2], me, gx, gy, dxqx, dyqy, cf, o2_r, o2_b, snu2);
-  }
-  if (STEADY || i >= 4) {
-    const int sb = 1 + (i & 1), sc = 3 + i % 3;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int slot = icx(q) == -1 ? 0 : (icx(q) == 0 ? sb : sc);
-      L.p1[0][slot][sw_grp_pos(q)][gl] = o_r[q];
-      L.p1[1][slot][sw_grp_pos(q)][gl] = o_b[q];
-    }
-  }
-  if (STEADY && lane_out) {
-    const long lo = g.at(R0 - CG_X2_WARM + i, c);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      __builtin_nontemporal_store(o2_r[q], &pn_r[q * g.plane + lo]);
-      __builtin_nontemporal_store(o2_b[q], &pn_b[q * g.plane + lo]);
-    }
-  }
-  __syncthreads();
-  // ---- B: level-2 pull of row m2 = m1 - 3 from the level-1 rows m2 + 1 (this iteration), m2, m2 - 1; reduce ----
-#pragma unroll
-  for (int q = 0; q < Q; ++q) s2[2][q] = s2[1][q], s2[1][q] = s2[0][q];
-#pragma unroll
-  for (int q = 0; q < 6; ++q) n2[2][q] = n2[1][q], n2[1][q] = n2[0][q];
-  if (STEADY || i >= 6) {
-    const int sb = 1 + ((i - 1) & 1), sc = 3 + (i - 2) % 3;
-    double fr[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int slot = icx(q) == -1 ? 0 : (icx(q) == 0 ? sb : sc);
-      int lsrc = gl - icy(q);
-      lsrc = lsrc < 0 ? 0 : (lsrc > LN - 1 ? LN - 1 : lsrc);
-      fr[q] = L.p1[0][slot][sw_grp_pos(q)][lsrc];
-      s2[0][q] = L.p1[1][slot][sw_grp_pos(q)][lsrc];
-    }
-    double psi, qx, qy;
-    cg_reduce_row(fr, s2[0], cf, n2[0], psi, qx, qy);
-    const int slot = i % 6;
-    L.ring2[0][slot][gl] = psi;
-    L.ring2[1][slot][gl] = qx;
-    L.ring2[2][slot][gl] = qy;
-  }
-}
-
-// MODE: bit 0 / bit 1 = the stencil loops of level 1 / level 2 unrolled (all 80 ring reads of a level in flight at once)
-template <int W, int MODE>
-__global__ __launch_bounds__(64 * W, 1) void k_cg_two_step(
-    double* __restrict__ pn_r, double* __restrict__ pn_b, const double* __restrict__ in_r,
-    const double* __restrict__ in_b, Geom g, CgFast cf, int row_begin, int row_end, int col_begin, int col_end,
-    int rows_per_chunk, int bstrips, int win0) {
-  constexpr int LN = 64 * W;
-  __shared__ CgX2Lds<W> L;
-  const int gl = threadIdx.x;
-  constexpr int S = LN - 2 * CG_X2_EDGE;  // output columns per block (a multiple of 16: windows stay line-aligned)
-  const int bs = blockIdx.x % bstrips, chunk = blockIdx.x / bstrips;
-  const int R0 = row_begin + chunk * rows_per_chunk;
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int c = win0 + bs * S + gl;
-  const bool lane_out = gl >= CG_X2_EDGE && gl < LN - CG_X2_EDGE && c >= col_begin && c < col_end;
-  const int cl = c < 1 ? 1 : (c > g.C - 2 ? g.C - 2 : c);
-  const int l0 = gl < 2 ? 0 : (gl > LN - 3 ? LN - 5 : gl - 2);  // stencil window of this lane, kept inside the ring
-  double raw_r[Q], raw_b[Q];
-  double s1[3][Q], n1[3][6];  // level 1: colour sums / (rho_r, rho_b, ux, uy, 1/rho, psi) of its last 3 rows, [0] = newest
-  double s2[3][Q], n2[3][6];  // level 2: of its last 3 rows (collided before the iteration's rotation)
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) s1[a][q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) n1[a][q] = 1.0;
-  }
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) s2[a][q] = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) n2[a][q] = 1.0;
-  }
-  {
-    const long o = g.at(R0 - 8, cl);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const long off = q * g.plane + (o - icx(q) * g.C - icy(q));
-      raw_r[q] = in_r[off];
-      raw_b[q] = in_b[off];
-    }
-  }
-  const int n_iter = (R1 - R0) + CG_X2_WARM;
-  for (int i = 0; i < CG_X2_WARM; ++i)
-    cg_two_step_iter<W, false, MODE>(L, raw_r, raw_b, s1, n1, s2, n2, pn_r, pn_b, in_r, in_b, g, cf, i, n_iter, R0, gl, l0, cl, c, lane_out);
-  for (int i = CG_X2_WARM; i < n_iter; ++i)
-    cg_two_step_iter<W, true, MODE>(L, raw_r, raw_b, s1, n1, s2, n2, pn_r, pn_b, in_r, in_b, g, cf, i, n_iter, R0, gl, l0, cl, c, lane_out);
-}
-#endif  // LBM_EXPERIMENTS
+#ifdef LBM_EXPERIMENTS  // two-phase step, two steps per pass (k_cg_two_step): csrc/experiments/cg_two_step.hpp
+#include "experiments/cg_two_step.hpp"
+#endif
 
 }  // namespace lbm

@@ -641,10 +641,17 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
     }
     // uniform row base (scalar registers) + this lane's 32-bit byte offset: the loads take the saddr form and no
     // 64-bit vector address arithmetic (one v_lshl_add_u64 per access before; the KBC window is VALU-bound)
+    // LDSR (the VALU-bound KBC window): the three byte offsets are made opaque per iteration -- otherwise the compiler
+    // folds them into 18 loop-invariant per-lane 64-bit pointers (36 VGPRs) and spends one v_lshl_add_u64 per access
+    // adding the row offset; opaque, every access is `global_load v, v_off32, s[row base]` with no VALU work at all
+    unsigned co[3] = {(unsigned)cols[0] * 8u, (unsigned)cols[1] * 8u, (unsigned)cols[2] * 8u};
+    if constexpr (LDSR) asm volatile("" : "+v"(co[0]), "+v"(co[1]), "+v"(co[2]));
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      const char* rowp = reinterpret_cast<const char*>(po + q * g.plane + g.at(rr[icx(q) + 1], 0));
-      nxt[q] = *reinterpret_cast<const double*>(rowp + (unsigned)cols[icy(q) + 1] * 8u);
+      long ro = q * g.plane + g.at(rr[icx(q) + 1], 0);
+      if constexpr (LDSR) asm volatile("" : "+s"(ro));  // the plane's row offset stays a scalar pair (scalar adds per access, no VALU)
+      const char* rowp = reinterpret_cast<const char*>(po + ro);
+      nxt[q] = *reinterpret_cast<const double*>(rowp + co[icy(q) + 1]);
     }
   }
   // ---- level 1 ---------------------------------------------------------------------------------
@@ -729,9 +736,23 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   const int rD = rbase + i - (D - 1);  // level D's row = level 1's row - (D-1)
   if (lane_ok && rD >= R0 && rD < R1) {
     const long o = g.at(rD, 0);
+    unsigned so = (unsigned)c_out * 8u;
+    if constexpr (LDSR) asm volatile("" : "+v"(so));
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(pn + q * g.plane + o) + (unsigned)c_out * 8u);
+      if constexpr (LDSR) {
+        // the plane's row base as an opaque SCALAR pair + this lane's 32-bit byte offset: `global_store v_off, v[data], s[base]`
+        // (left to itself the compiler adds the lane offset to pn first -- one per-lane 64-bit pointer -- and then pays a
+        // v_lshl_add_u64 per plane)
+        unsigned long base = reinterpret_cast<unsigned long>(pn) + (unsigned long)((q * g.plane + o) * 8);
+        asm volatile("" : "+s"(base));
+        typedef __attribute__((address_space(1))) double gdouble;
+        gdouble* gp = reinterpret_cast<gdouble*>(base + so);
+        if (NT_STORE) __builtin_nontemporal_store(f[q], gp);
+        else *gp = f[q];
+        continue;
+      }
+      double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(pn + q * g.plane + o) + so);
       if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
       else *dst = f[q];
     }
@@ -741,59 +762,9 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   (void)c_load;
 }
 
-#ifdef LBM_EXPERIMENTS
-// The same iteration with the level-1 inputs prefetched TWO rows ahead (plain edges only): three raw-row
-// buffers rotate with the unroll index K -- buffer K holds this iteration's row (loaded two iterations ago),
-// buffer (K + 2) % 3, consumed by the previous iteration, takes row i + 2.  One wave per SIMD leaves the
-// registers for it (18 more), and nothing else hides a late row.
-template <class Model, int D, int K, bool NT_STORE>
-__device__ __forceinline__ void sw_iteration_pf2(double (&ring)[D > 1 ? D - 1 : 1][3][Q], double (&raw)[3][Q],
-                                                 double* __restrict__ pn, const double* __restrict__ po,
-                                                 const Geom& g, const Model& m, int i, int rbase, int R0,
-                                                 int R1, const int (&cols)[3], bool lane_ok, int c_out) {
-  {
-    const int r1n = rbase + i + 2;
-    int rr[3] = {r1n + 1, r1n, r1n - 1};  // rows supplying cx = -1, 0, +1
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (g.ghost) rr[k] = rr[k] < -g.ghost ? -g.ghost : (rr[k] > g.R + g.ghost - 1 ? g.R + g.ghost - 1 : rr[k]);
-      else rr[k] = rr[k] < 0 ? rr[k] + g.R : (rr[k] >= g.R ? rr[k] - g.R : rr[k]);
-      if (!g.ghost) rr[k] = rr[k] >= g.R ? rr[k] - g.R : rr[k];  // two rows ahead may wrap twice on tiny lattices
-    }
-    constexpr int KN = (K + 2) % 3;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) raw[KN][q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
-  }
-  double f[Q], rho, ux, uy;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) f[q] = raw[K][q];
-  m.collide(f, rho, ux, uy);
-#pragma unroll
-  for (int l = 2; l <= D; ++l) {
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ring[l - 2][K][q] = f[q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int slot = icx(q) == -1 ? K : (icx(q) == 0 ? (K + 2) % 3 : (K + 1) % 3);
-      double v = ring[l - 2][slot][q];
-      if (icy(q) == 1) v = lane_from_prev(v);
-      else if (icy(q) == -1) v = lane_from_next(v);
-      f[q] = v;
-    }
-    m.collide(f, rho, ux, uy);
-  }
-  const int rD = rbase + i - (D - 1);
-  if (lane_ok && rD >= R0 && rD < R1) {
-    const long o = g.at(rD, c_out);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      double* dst = pn + q * g.plane + o;
-      if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
-      else *dst = f[q];
-    }
-  }
-}
-#endif  // LBM_EXPERIMENTS
+#ifdef LBM_EXPERIMENTS  // sliding window with the level-1 rows prefetched two iterations ahead (sw_iteration_pf2): csrc/experiments/sw_prefetch2.hpp
+#include "experiments/sw_prefetch2.hpp"
+#endif
 
 // Register budget (ring 54*(D-1) VGPRs + prefetch 18 + working set) -> waves per SIMD the kernel
 // is compiled for: D = 2: 4, D = 3: 3, D = 4, 5: 2, deeper: 1 (only enforced for 4-wave blocks).
@@ -961,183 +932,9 @@ __global__ __launch_bounds__(128, 1) void k_stream_collide_sw_walls(double* __re
   }
 }
 
-#ifdef LBM_EXPERIMENTS  // measured and not kept (DESIGN.md "experiments"): compiled only with make EXPERIMENTS=1
-// ---- paired strips: the waves of a workgroup own ADJACENT 64-column windows and hand each other the edge
-// columns of every level through LDS, so only the outer 2 (D - 1) columns of the GROUP are redundant: 120 of
-// 128 lanes (2 waves) or 248 of 256 (4 waves) produce output instead of 56 of 64, and a group's rows are read
-// as one 1 - 2 KB run instead of 512-byte pieces whose 128-byte lines neighbouring strips fetch again.
-// Schedule: level l lags level l-1 by TWO rows (level l at iteration i computes row rbase + i - 2 (l - 1)), so
-// everything a level pulls from the level below -- rows r-1, r, r+1 -- was computed in EARLIER iterations: the
-// edge values published in iteration i are first read in iteration i + 1 and ONE workgroup barrier per
-// iteration orders them (with a one-row lag the c_x = -1 populations would come from the row computed in the
-// same iteration: a barrier per level).  Price: a 4-row register ring per level (288 VGPRs at D = 5; one wave
-// per SIMD has them) and D - 1 more pipeline iterations per chunk.  A lane without a source lane in a DPP
-// wave shift keeps the `old` operand: that operand is the neighbour wave's edge value read from LDS, so the
-// hand-off costs no select.  Same arithmetic per node as every other path: identical bits.
-template <int D>
-struct SwpExch {
-  double v[D - 1][4][2][3];  // [level produced][ring slot][0: a wave's lane 0 (q = 4,7,8) / 1: its lane 63 (q = 2,5,6)][j]
-};
-__device__ __forceinline__ double lane_from_prev_fill(double v, double fill) {  // lane i <- lane i-1; lane 0 <- fill
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
-  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x138, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lane_from_next_fill(double v, double fill) {  // lane i <- lane i+1; lane 63 <- fill
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
-  hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, 0x130, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-__host__ __device__ constexpr int swp_q_side0(int j) { return j == 0 ? 4 : (j == 1 ? 7 : 8); }  // icy = -1: wanted by the wave on the left
-__host__ __device__ constexpr int swp_q_side1(int j) { return j == 0 ? 2 : (j == 1 ? 5 : 6); }  // icy = +1: wanted by the wave on the right
-__host__ __device__ constexpr int swp_j_of(int q) { return (q == 4 || q == 2) ? 0 : ((q == 7 || q == 5) ? 1 : 2); }
-
-template <class Model, int D, int WAVES, int K4, bool NT_STORE>
-__device__ __forceinline__ void swp_iteration(double (&ring)[D - 1][4][Q], double (&cur)[Q], SwpExch<D>* ex,
-                                              double* __restrict__ pn, const double* __restrict__ po, const Geom& g,
-                                              const Model& m, int i, int n_iter, int rbase, int R0, int R1,
-                                              const int (&cols)[3], bool lane_ok, int c_out, int w, int lane,
-                                              int last_row_needed) {
-  if (i >= n_iter) return;  // workgroup-uniform (all waves of a group share the chunk)
-  __syncthreads();          // the edge values published in iteration i - 1 are visible; those read then are consumed
-  // ---- the neighbours' edge values every level of this iteration pulls: all from EARLIER iterations (ring slots
-  // K4+1 .. K4+3), read in one batch before this iteration publishes anything (slot K4) ---------------------------
-  double e[D - 1][6];  // [level l - 2][0..2: q = 2,5,6 from the left wave's lane 63 | 3..5: q = 4,7,8 from the right wave's lane 0]
-#pragma unroll
-  for (int l = 2; l <= D; ++l) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int q1 = swp_q_side1(j), q0 = swp_q_side0(j);
-      const int s1 = icx(q1) == -1 ? (K4 + 3) % 4 : (icx(q1) == 0 ? (K4 + 2) % 4 : (K4 + 1) % 4);
-      const int s0 = icx(q0) == -1 ? (K4 + 3) % 4 : (icx(q0) == 0 ? (K4 + 2) % 4 : (K4 + 1) % 4);
-      e[l - 2][j] = ex[w > 0 ? w - 1 : 0].v[l - 2][s1][1][j];
-      e[l - 2][3 + j] = ex[w < WAVES - 1 ? w + 1 : WAVES - 1].v[l - 2][s0][0][j];
-    }
-  }
-  // ---- prefetch level-1 inputs of the NEXT iteration ------------------------------------------------------------
-  double nxt[Q];
-  {
-    const int r1n = rbase + i + 1;
-    int rr[3] = {r1n + 1, r1n, r1n - 1};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (g.ghost) rr[k] = rr[k] < -g.ghost ? -g.ghost : (rr[k] > g.R + g.ghost - 1 ? g.R + g.ghost - 1 : rr[k]);
-      else {
-        rr[k] = rr[k] < 0 ? rr[k] + g.R : (rr[k] >= g.R ? rr[k] - g.R : rr[k]);
-        rr[k] = rr[k] >= g.R ? rr[k] - g.R : rr[k];
-      }
-    }
-    if (r1n <= last_row_needed) {
-#pragma unroll
-      for (int q = 0; q < Q; ++q) nxt[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
-    } else {
-#pragma unroll
-      for (int q = 0; q < Q; ++q) nxt[q] = 1.0;
-    }
-  }
-  double f[Q], rho, ux, uy;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) f[q] = cur[q];
-  m.collide(f, rho, ux, uy);
-#pragma unroll
-  for (int l = 2; l <= D; ++l) {
-    // publish level l-1's row of this iteration: ring slot K4; its edge lanes go to the neighbours
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ring[l - 2][K4][q] = f[q];
-    if (lane == 0) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) ex[w].v[l - 2][K4][0][j] = f[swp_q_side0(j)];
-    }
-    if (lane == 63) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) ex[w].v[l - 2][K4][1][j] = f[swp_q_side1(j)];
-    }
-    // gather level l's row r = rbase + i - 2 (l - 1) from level l-1's rows r+1, r, r-1 = ring slots K4+3, K4+2, K4+1
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      const int slot = icx(q) == -1 ? (K4 + 3) % 4 : (icx(q) == 0 ? (K4 + 2) % 4 : (K4 + 1) % 4);
-      double v = ring[l - 2][slot][q];
-      if (icy(q) == 1) v = lane_from_prev_fill(v, w > 0 ? e[l - 2][swp_j_of(q)] : v);             // from column c-1
-      else if (icy(q) == -1) v = lane_from_next_fill(v, w < WAVES - 1 ? e[l - 2][3 + swp_j_of(q)] : v);  // from column c+1
-      f[q] = v;
-    }
-    m.collide(f, rho, ux, uy);
-  }
-  const int rD = rbase + i - 2 * (D - 1);
-  if (lane_ok && rD >= R0 && rD < R1) {
-    const long o = g.at(rD, c_out);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      double* dst = pn + q * g.plane + o;
-      if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
-      else *dst = f[q];
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < Q; ++q) cur[q] = nxt[q];
-}
-
-__host__ __device__ constexpr int swp_group_width(int D, int WAVES) { return 64 * WAVES - 2 * (D - 1); }
-
-template <class Model, int D, int WAVES, bool NT_STORE>
-__global__ __launch_bounds__(64 * WAVES, 1) void k_stream_collide_swp(
-    double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin, int row_end,
-    int rows_per_chunk, int groups, int n_groups_total, int chunk_stride) {
-  constexpr int GW = swp_group_width(D, WAVES);
-  __shared__ SwpExch<D> ex[WAVES];
-  const int grp = blockIdx.x;  // one workgroup = one group of adjacent windows on one chunk of rows
-  if (grp >= n_groups_total) return;
-  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int gs = grp % groups, chunk = grp / groups;
-  const int R0 = row_begin + chunk * (chunk_stride > 0 ? chunk_stride : rows_per_chunk);
-  const int R1 = R0 + rows_per_chunk < row_end ? R0 + rows_per_chunk : row_end;
-  const int gl = 64 * w + lane;                      // lane index inside the group
-  int c = gs * GW - (D - 1) + gl;                    // this lane's column at every level
-  const bool lane_ok = gl >= D - 1 && gl < D - 1 + GW && c < g.C;
-  c = c < 0 ? c + g.C : (c >= g.C ? c - g.C : c);
-  c = c >= g.C ? c - g.C : c;                        // the last group may run more than one period past the edge
-  const int cols[3] = {wrap_col(g, c + 1), c, wrap_col(g, c - 1)};
-  const int rbase = R0 - (D - 1);
-  const int n_iter = (R1 - R0) + 3 * (D - 1);
-  const int last_row_needed = R1 - 1 + (D - 1);      // level-1 rows beyond it feed nothing that is stored
-  double ring[D - 1][4][Q];
-#pragma unroll
-  for (int a = 0; a < D - 1; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) ring[a][b][q] = 1.0;  // warm-up garbage, never stored
-  if (lane < 3) {  // the exchange slots the first iterations read before anything was published
-#pragma unroll
-    for (int a = 0; a < D - 1; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        ex[w].v[a][b][0][lane] = 1.0;
-        ex[w].v[a][b][1][lane] = 1.0;
-      }
-  }
-  double cur[Q];
-  {  // level-1 inputs of iteration 0
-    int rr[3] = {rbase + 1, rbase, rbase - 1};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (g.ghost) rr[k] = rr[k] < -g.ghost ? -g.ghost : (rr[k] > g.R + g.ghost - 1 ? g.R + g.ghost - 1 : rr[k]);
-      else rr[k] = rr[k] < 0 ? rr[k] + g.R : (rr[k] >= g.R ? rr[k] - g.R : rr[k]);
-    }
-#pragma unroll
-    for (int q = 0; q < Q; ++q) cur[q] = po[q * g.plane + g.at(rr[icx(q) + 1], 0) + cols[icy(q) + 1]];
-  }
-  for (int i = 0; i < n_iter; i += 4) {  // unrolled by the 4 ring slots: every register index is static
-    swp_iteration<Model, D, WAVES, 0, NT_STORE>(ring, cur, ex, pn, po, g, m, i, n_iter, rbase, R0, R1, cols, lane_ok, c, w, lane, last_row_needed);
-    swp_iteration<Model, D, WAVES, 1, NT_STORE>(ring, cur, ex, pn, po, g, m, i + 1, n_iter, rbase, R0, R1, cols, lane_ok, c, w, lane, last_row_needed);
-    swp_iteration<Model, D, WAVES, 2, NT_STORE>(ring, cur, ex, pn, po, g, m, i + 2, n_iter, rbase, R0, R1, cols, lane_ok, c, w, lane, last_row_needed);
-    swp_iteration<Model, D, WAVES, 3, NT_STORE>(ring, cur, ex, pn, po, g, m, i + 3, n_iter, rbase, R0, R1, cols, lane_ok, c, w, lane, last_row_needed);
-  }
-}
-
-#endif  // LBM_EXPERIMENTS
+#ifdef LBM_EXPERIMENTS  // sliding window on paired strips (k_stream_collide_swp): csrc/experiments/sw_paired_strips.hpp
+#include "experiments/sw_paired_strips.hpp"
+#endif
 
 // Edge pass: recompute the boundary nodes (rows 0 / R-1 where they carry a fix-up, columns
 // 0 / C-1 where they do) with the full boundary gather and overwrite what the interior

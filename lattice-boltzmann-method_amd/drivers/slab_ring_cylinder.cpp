@@ -20,7 +20,7 @@
 //                      else, and all slabs finish a block together); --uniform 1: N equal slabs (the cylinder then
 //                      straddles a seam of the BASELINE layout); --slab-rows r0,r1,...: heights by hand;
 //                      --costs far_us_per_row,owner_us,owner_us_per_row: the planner's cost model instead of its table
-//                      --form reference|reassociated: the collision's operation order (default: the library's, i.e. bitwise to the oracle)
+//                      --form reference|reassociated: the collision's operation order (default: the library's = reassociated; reference = bitwise to the oracle)
 //   RANK=i WORLD_SIZE=N LOCAL_RANK=i slab_ring_cylinder --id-file /tmp/x ...
 //
 // tau = 0.55 (parameters.toml), u_in = 0.04 (SURVEY 8d allows a smaller u for the benchmark), markers
@@ -448,10 +448,10 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "--form reference|reassociated\n");
       return 2;
     }
-    // the planner's table is measured with the reference-order collision; the reassociated one walks a far row in
-    // 0.157 us instead of 0.180 (4096 columns, 5 steps) and its owner block costs 326 us + 0.12 us per row: unless
-    // --costs says otherwise
-    if (a.form == LBM_FORM_REASSOCIATED && a.costs.empty()) a.costs = "0.157,326,0.12";
+    // the planner's built-in table is measured with the reference-order collision; the reassociated one -- the library's
+    // default since round 4 -- walks a far row in 0.157 us instead of 0.180 (4096 columns, 5 steps) and its owner block
+    // costs 326 us + 0.12 us per row: unless --costs says otherwise
+    if (a.form != LBM_FORM_REFERENCE_ORDER && a.costs.empty()) a.costs = "0.157,326,0.12";
   }
   a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.diameter = std::atoi(arg_value(argc, argv, "--diameter", "300").c_str());

@@ -25,7 +25,7 @@
 namespace {
 
 struct Args {
-  int rows = 2048, cols = 2048, steps = 50, warmup = 5, edge_rows = 16, check = 0, emulate = 0, one_gpu = 0;
+  int rows = 2048, cols = 2048, steps = 50, warmup = 5, edge_rows = 16, check = 0, emulate = 0, one_gpu = 0, parts = 1;
   std::string id_file;
 };
 
@@ -203,10 +203,16 @@ int run_emulated(const Args& a, int N) {
     for (int side = 0; side < 2; ++side)
       for (int k = 0; k < 2; ++k) check(lbm_malloc((void**)&S[r].buf[side][k], 2 * msg * 8), "lbm_malloc");
   }
-  auto pack = [&](int r, int cur) {
+  // the ring's two streams: edge (frame of the slab, pack, exchange) beside main (the inner rectangle)
+  lbm_stream_t edge = nullptr;
+  check(lbm_stream_create(&edge), "lbm_stream_create");
+  void *ev_fork = nullptr, *ev_join = nullptr;
+  check(lbm_event_create(&ev_fork), "lbm_event_create");
+  check(lbm_event_create(&ev_join), "lbm_event_create");
+  auto pack = [&](int r, int cur, lbm_stream_t st) {
     for (int k = 0; k < 2; ++k) {
-      if (r > 0) check(lbm_halo_pack(S[r].buf[0][0] + k * msg, S[r].lat[cur][k], &g, LBM_HALO_TWO_PHASE, 0, nullptr), "lbm_halo_pack");
-      if (r < N - 1) check(lbm_halo_pack(S[r].buf[1][0] + k * msg, S[r].lat[cur][k], &g, LBM_HALO_TWO_PHASE, 1, nullptr), "lbm_halo_pack");
+      if (r > 0) check(lbm_halo_pack(S[r].buf[0][0] + k * msg, S[r].lat[cur][k], &g, LBM_HALO_TWO_PHASE, 0, st), "lbm_halo_pack");
+      if (r < N - 1) check(lbm_halo_pack(S[r].buf[1][0] + k * msg, S[r].lat[cur][k], &g, LBM_HALO_TWO_PHASE, 1, st), "lbm_halo_pack");
     }
   };
   auto deliver = [&]() {
@@ -222,26 +228,41 @@ int run_emulated(const Args& a, int N) {
     }
   };
   int cur = 0;
-  for (int r = 0; r < N; ++r) pack(r, cur);
+  for (int r = 0; r < N; ++r) pack(r, cur, nullptr);
   deliver();
   for (int r = 0; r < N; ++r) unpack(r, cur);
   std::vector<void*> ev(2 * N, nullptr);
   for (auto& e : ev) check(lbm_event_create(&e), "lbm_event_create");
   for (int i = 0; i < a.warmup + a.steps; ++i) {
-    for (int r = 0; r < N; ++r) {  // a slab's step: edge rows, interior rows, messages packed (what lbm_ring_cg_step enqueues)
+    for (int r = 0; r < N; ++r) {  // a slab's step as lbm_ring_cg_step enqueues it
       check(lbm_event_record(ev[2 * r], nullptr), "event");
       auto rows = [&](int r0, int r1) {
         check(lbm_cg_step_fused(S[r].lat[cur ^ 1][0], S[r].lat[cur ^ 1][1], S[r].lat[cur][0], S[r].lat[cur][1], &g, &S[r].bc, &prm, r0, r1,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr), "lbm_cg_step_fused");
       };
-      if (N > 1) {
+      auto part = [&](int which, lbm_stream_t st) {
+        check(lbm_cg_step_fused_part(S[r].lat[cur ^ 1][0], S[r].lat[cur ^ 1][1], S[r].lat[cur][0], S[r].lat[cur][1], &g, &S[r].bc, &prm, which, E,
+                                     nullptr, nullptr, nullptr, nullptr, nullptr, st), "lbm_cg_step_fused_part");
+      };
+      if (N > 1 && a.parts) {
+        // frame (wall / copy columns + the first and last edge rows) and the messages on the edge stream, the inner
+        // rectangle on the main stream beside them; the step ends when both have
+        check(lbm_event_record(ev_fork, nullptr), "event");
+        check(lbm_stream_wait_event(edge, ev_fork), "wait");
+        part(LBM_CG_PART_FRAME, edge);
+        part(LBM_CG_PART_INNER, nullptr);
+        pack(r, cur ^ 1, edge);
+        check(lbm_event_record(ev_join, edge), "event");
+        check(lbm_stream_wait_event(nullptr, ev_join), "wait");
+      } else if (N > 1) {  // round 3: three row ranges, each a frame + inner pair
         rows(0, E);
         rows(R - E, R);
         rows(E, R - E);
+        pack(r, cur ^ 1, nullptr);
       } else {
         rows(0, R);
+        pack(r, cur ^ 1, nullptr);
       }
-      pack(r, cur ^ 1);
       check(lbm_event_record(ev[2 * r + 1], nullptr), "event");
     }
     deliver();
@@ -254,6 +275,10 @@ int run_emulated(const Args& a, int N) {
     cur ^= 1;
   }
   for (auto& e : ev) lbm_event_destroy(e);
+  lbm_event_destroy(ev_fork);
+  lbm_event_destroy(ev_join);
+  check(lbm_stream_sync(edge), "sync");
+  lbm_stream_destroy(edge);
   int bad = 0;
   if (a.check) {
     lbm_geom gw{Rg, C, 0, 0};
@@ -310,6 +335,7 @@ int main(int argc, char** argv) {
   a.steps = std::atoi(arg_value(argc, argv, "--steps", "50").c_str());
   a.warmup = std::atoi(arg_value(argc, argv, "--warmup", "5").c_str());
   a.edge_rows = std::atoi(arg_value(argc, argv, "--edge-rows", "16").c_str());
+  a.parts = std::atoi(arg_value(argc, argv, "--parts", "1").c_str());  // 0: the emulated chain with round 3's three row ranges per step
   a.check = std::atoi(arg_value(argc, argv, "--check", "0").c_str());
   a.emulate = std::atoi(arg_value(argc, argv, "--emulate", "0").c_str());
   a.one_gpu = std::atoi(arg_value(argc, argv, "--one-gpu", "0").c_str());

@@ -628,7 +628,7 @@ def test_sliding_window_carries_walls(lib, oracle, case):
         bc.col_lo = bc.col_hi = pylbm.EDGE_SPECULAR
         bc.uw_r = 0.04
         if case == "channel_delta":
-            prm = pylbm.BgkParams(1.3, 0, 1)
+            prm = pylbm.BgkParams(1.3, 0, 1, form=pylbm.FORM_REFERENCE_ORDER)
     for R, C in ((96, 150), (70, 64), (130, 420)):
         f0 = random_state(oracle, R, C, seed=3)
         g = pylbm.Geom(R, C, 0)

@@ -311,8 +311,10 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                  (51, 40), (51, 16), (52, 9), (52, 64), (52, 24),      # 51 / 52: the walking block (cg_strip2 = 41 / 42: 4 x 1, 6 x 1 waves)
                  (53, 40), (54, 33), (55, 64), (56, 40), (56, 7), (57, 40), (57, 9),  # ... 2 x 2, 3 x 2, 2 x 3, 2 x 1, 3 x 1 waves
                  (61, 40), (61, 16),                                   # 61: 4 x 1 without prefetch (cg_walk_pf = 0), 4 waves per SIMD
-                 (101, 64), (102, 64), (103, 64), (104, 64),           # 100 + s: several nodes per thread (cg_big = s), k_cg_tile_mn
-                 (105, 64), (106, 64), (107, 64), (108, 64)]
+                 (102, 64),                                            # 102: k_cg_tile_mn, 16 x 64 tiles, 2 nodes per thread (cg_big = 2: the default)
+                 (102, 202), (102, 404), (102, 801), (102, 2)]         # ... with rows >= 100 / = 2: "cg_big_xcd" = rows (patch orders / pairs)
+        if lib.raw.lbm_build_has_experiments():                       # the other shapes of the round-4 sweep
+            cases += [(101, 64), (103, 64), (104, 64), (105, 64), (106, 64), (107, 64), (108, 64), (109, 64), (106, 208), (101, 303)]
         if lib.raw.lbm_build_has_experiments():                       # the strip kernels, generations 1 - 5 (make EXPERIMENTS=1)
             cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33),
                       (21, 40), (22, 9),                               # 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
@@ -321,6 +323,7 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         for strip, rows in cases:
             big, strip = (strip - 100, 0) if strip > 100 else (0, strip)
             lib.set_tuning(b"cg_big", big)
+            lib.set_tuning(b"cg_big_xcd", rows if (big and (rows >= 100 or rows == 2)) else -1)
             lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
             lib.set_tuning(b"cg_strip2", 41 if strip == 61 else (strip - 10 if strip >= 10 else 0))
             lib.set_tuning(b"cg_walk_pf", 0 if strip == 61 else -1)
@@ -341,6 +344,7 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                 assert lib.raw.lbm_cg_last_inner_form() == want, (strip, rows, lib.raw.lbm_cg_last_inner_form())
     finally:
         lib.set_tuning(b"cg_big", -1)
+        lib.set_tuning(b"cg_big_xcd", -1)
         lib.set_tuning(b"cg_strip", -1)
         lib.set_tuning(b"cg_strip2", -1)
         lib.set_tuning(b"cg_walk_pf", -1)
@@ -351,6 +355,54 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
     for key, val in res.items():
         for k in range(2):
             assert torch.equal(val[k], ref[k]), (key, k, float((val[k] - ref[k]).abs().max()))
+
+
+@pytest.mark.parametrize("R,C,edge", [(256, 200, 16), (130, 1040, 3), (64, 32, 16), (200, 544, 40)])
+def test_cg_step_in_two_parts_equals_one_call(lib, oracle, R, C, edge):
+    """lbm_cg_step_fused_part: FRAME (boundary-gather kernel on the lattice's frame widened to the first / last `edge` rows)
+    + INNER (plain-offset kernel on the rest) write disjoint nodes and are together lbm_cg_step_fused on [0, R) -- on a
+    single block and on a slab with ghost rows and HALO edges (what lbm_ring_cg_step enqueues on its two streams)"""
+    import ctypes as ct
+    from gpu_util import dev, upload_soa
+    from pylbm import _ptr
+    po = pyoracle.cg_params(R, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    bc = pylbm.Bc()
+    lib.raw.lbm_cg_default_bc(ct.byref(bc))
+    flat = pylbm.Geom(R, C, 0)
+    f_r, f_b = upload_soa(lib, s0["f_r"]), upload_soa(lib, s0["f_b"])
+    rr, rb, uu = upload_soa(lib, s0["rho_r"]), upload_soa(lib, s0["rho_b"]), upload_soa(lib, s0["u"])
+    p0 = [torch.empty((9, R, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+    lib.cg_collide(_ptr(p0[0]), _ptr(p0[1]), _ptr(f_r), _ptr(f_b), _ptr(rr), _ptr(rb), _ptr(uu),
+                   ct.byref(flat), ct.byref(bc), ct.byref(pg), None, None, None)
+    for ghost in (0, 3):
+        geom = pylbm.Geom(R, C, ghost)
+        b2 = pylbm.Bc()
+        lib.raw.lbm_cg_default_bc(ct.byref(b2))
+        if ghost:
+            b2.row_lo = b2.row_hi = pylbm.EDGE_HALO
+        def lattice():
+            t = [torch.zeros((9, R + 2 * ghost, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+            for k in range(2):
+                t[k][:, ghost:ghost + R] = p0[k]
+                if ghost:   # any finite numbers: both forms read the same ghost rows
+                    t[k][:, :ghost] = p0[k][:, R - ghost:]
+                    t[k][:, ghost + R:] = p0[k][:, :ghost]
+            return t
+        a, want = lattice(), lattice()
+        lib.cg_step_fused(_ptr(want[0]), _ptr(want[1]), _ptr(a[0]), _ptr(a[1]), ct.byref(geom), ct.byref(b2), ct.byref(pg), 0, R,
+                          None, None, None, None, None, None)
+        got = lattice()
+        s2 = torch.cuda.Stream()
+        torch.cuda.synchronize()
+        lib.cg_step_fused_part(_ptr(got[0]), _ptr(got[1]), _ptr(a[0]), _ptr(a[1]), ct.byref(geom), ct.byref(b2), ct.byref(pg),
+                               pylbm.CG_PART_FRAME, edge, None, None, None, None, None, ct.c_void_p(s2.cuda_stream))
+        lib.cg_step_fused_part(_ptr(got[0]), _ptr(got[1]), _ptr(a[0]), _ptr(a[1]), ct.byref(geom), ct.byref(b2), ct.byref(pg),
+                               pylbm.CG_PART_INNER, edge, None, None, None, None, None, None)
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(got[k][:, ghost:ghost + R], want[k][:, ghost:ghost + R]), (ghost, k)
 
 
 # ---- row a13: class differential (src/differential.hpp:48-51, src/differential.cpp:23-39) --------

@@ -36,7 +36,7 @@ def test_config5_fullsize_ibm_block_vs_oracle(lib, oracle):
     del u0
     bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=pylbm.EDGE_SPECULAR,
                   col_hi=pylbm.EDGE_SPECULAR, uw_r=u_in)
-    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1), bc=bc)
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1, form=pylbm.FORM_REFERENCE_ORDER), bc=bc)
     ib = pylbm.Ibm(lib, x, y, X, Y)
     sv.attach_ibm(ib)
     sv.set_f(f0)
@@ -82,25 +82,29 @@ def test_config4_fullsize_two_phase_step_vs_oracle(lib, oracle, mode):
 
 
 @pytest.mark.parametrize("form", [41, 42])
-def test_config4_fullsize_walking_block_equals_tile_kernel(lib, oracle, form):
-    """8192 x 2048, 4 iterations through lbm_cg_solver_step: the opt-in walking block (cg_strip2 = 41 / 42: 22 chunks of
-    34 strips, XCD-contiguous order, 32-bit plane offsets) leaves the SAME BITS as the default tile kernel -- populations
-    of both colours and every observable field -- and it is the form that ran."""
+def test_config4_fullsize_inner_kernels_leave_the_same_bits(lib, oracle, form):
+    """8192 x 2048, 4 iterations through lbm_cg_solver_step: the default (round 4: 16 x 64 tiles, two nodes per thread,
+    patches of 8 x 2 tiles per XCD -- form 102), round 3's 16 x 32 tile kernel (cg_big = 0) and the opt-in walking block
+    (cg_big = 0, cg_strip2 = 41 / 42: 22 chunks of 34 strips, XCD-contiguous order, 32-bit plane offsets) leave the SAME
+    BITS -- populations of both colours and every observable field -- and each is the form that ran."""
     R, C, n = 8192, 2048, 4
     po = pyoracle.cg_params(R, C)
     pg = pylbm.cg_params()
     s0 = oracle.cg_init(po)
     got = {}
     try:
-        for f in (0, form):
-            lib.set_tuning(b"cg_strip2", f)
+        for big, strip2, want in ((-1, -1, 102), (0, 0, 0), (0, form, form)):
+            lib.set_tuning(b"cg_big", big)
+            lib.set_tuning(b"cg_strip2", strip2)
             sv = pylbm.CgSolver(lib, R, C, pg)
             sv.set_state(s0["f_r"], s0["f_b"], s0["rho_r"], s0["rho_b"], s0["u"])
             sv.step(n)
-            got[f] = sv.get_state()
-            assert lib.raw.lbm_cg_last_inner_form() == f
+            got[want] = sv.get_state()
+            assert lib.raw.lbm_cg_last_inner_form() == want
             sv.close()
     finally:
         lib.set_tuning(b"cg_strip2", -1)
-    for k in got[0]:
-        assert bits_equal(got[form][k], got[0][k]), (k, ulp_diff(got[form][k], got[0][k]))
+        lib.set_tuning(b"cg_big", -1)
+    for f in (0, form):
+        for k in got[102]:
+            assert bits_equal(got[f][k], got[102][k]), (f, k, ulp_diff(got[f][k], got[102][k]))

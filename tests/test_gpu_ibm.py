@@ -52,12 +52,14 @@ def test_eulerian_force_density_vs_oracle(lib, oracle):
     ib.close()
 
 
-def cylinder_solver(lib, X, Y, omega, u_in, x, y):
+def cylinder_solver(lib, X, Y, omega, u_in, x, y, form=pylbm.FORM_REFERENCE_ORDER):
+    """the cylinder preset; the parity tests hold it to the oracle BITWISE, i.e. in the reference's operation order
+    (the library's default is the reassociated collision: test_cylinder_with_the_default_collision)"""
     bc = pylbm.Bc.periodic()
     bc.row_lo = bc.row_hi = pylbm.EDGE_ABB_VELOCITY      # cylinder_test.cpp:135-154
     bc.col_lo = bc.col_hi = pylbm.EDGE_SPECULAR          # :157-163
     bc.uw_r, bc.uw_c = u_in, 0.0
-    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1), bc=bc)
+    sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1, form=form), bc=bc)
     ib = pylbm.Ibm(lib, x, y, X, Y)
     sv.attach_ibm(ib)
     return sv, ib
@@ -120,7 +122,7 @@ def test_cylinder_two_slabs_equal_single_block(lib, oracle, owner):
     f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
     fo, uo, rhoo, Fso = oracle.cylinder_steps(x, y, f0, omega, u_in, n)
     d = dev()
-    prm = pylbm.BgkParams(omega, 0, 1)
+    prm = pylbm.BgkParams(omega, 0, 1, form=pylbm.FORM_REFERENCE_ORDER)
     a, b = 1.0 / 3.0, 1.0 / 9.0
 
     def mkbc(lo, hi):
@@ -195,7 +197,7 @@ def test_moving_boundary_extension(lib, oracle):
     f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
 
     def run(Ub):
-        sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1), bc=bc)
+        sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, pylbm.BgkParams(omega, 0, 1, form=pylbm.FORM_REFERENCE_ORDER), bc=bc)
         ib = pylbm.Ibm(lib, x, y, X, Y)
         if Ub is not None:
             lib.ibm_set_velocity(ib.h, ct.c_double(Ub[0]), ct.c_double(Ub[1]))
@@ -283,27 +285,27 @@ def test_forced_box_variants_equal_the_oracle(lib, oracle, tune, cy_frac):
     assert np.allclose(Fs, Fso, rtol=1e-11, atol=1e-16)
 
 
-def test_cylinder_with_reassociated_delta_form(lib, oracle):
-    """Opt-in (tuning bgk_fast_delta = 1): the cylinder preset's delta-form collision through the
-    reassociated model -- not bitwise any more, 1e-10 relative on f after 13 steps (north star: 1e-8)."""
+def test_cylinder_with_the_default_collision(lib, oracle):
+    """LBM_FORM_DEFAULT (round 4: one rule -- the reassociated collision everywhere, the delta form included): the
+    cylinder preset is not bitwise then, 1e-10 relative on f after 13 steps (north star: 1e-8); and DEFAULT and
+    LBM_FORM_REASSOCIATED are the same bits."""
     X, Y, omega, u_in, radius = 160, 128, 1.0 / 0.55, 0.05, 8.0
     x, y = circle(X * 0.5 + 0.3, Y / 2.0 - 0.4, radius)
     u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
     f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
     fo, uo, rhoo, Fso = oracle.cylinder_steps(x, y, f0, omega, u_in, 13)
-    try:
-        lib.set_tuning(b"bgk_fast_delta", 1)
-        lib.set_tuning(b"bgk_fast", 1)
-        sv, ib = cylinder_solver(lib, X, Y, omega, u_in, x, y)
+    res = {}
+    for form in (pylbm.FORM_DEFAULT, pylbm.FORM_REASSOCIATED):
+        sv, ib = cylinder_solver(lib, X, Y, omega, u_in, x, y, form=form)
         sv.set_f(f0)
         sv.step(13, record_moments=False)
-        f, Fs = sv.get_f(), ib.surface_force()
+        res[form] = (sv.get_f(), ib.surface_force())
         sv.close(); ib.close()
-    finally:
-        lib.set_tuning(b"bgk_fast_delta", -1)
-        lib.set_tuning(b"bgk_fast", -1)
+    f, Fs = res[pylbm.FORM_DEFAULT]
     assert relerr(f, fo) < 1e-10, relerr(f, fo)
+    assert not bits_equal(f, fo)                       # (it really is the other operation order)
     assert np.allclose(Fs, Fso, rtol=1e-8, atol=1e-14)
+    assert bits_equal(f, res[pylbm.FORM_REASSOCIATED][0])
 
 
 # ---- config 5 over slabs in blocks of D steps, the boundary anywhere -- also across a seam -------------
@@ -316,7 +318,7 @@ def _slab_block_run(lib, oracle, X, Y, n_slabs, cx, radius, D, n_blocks, start_f
     x, y = circle(cx, Y / 2 + 0.21, radius)
     u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
     f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
-    prm = pylbm.BgkParams(omega, 0, 1)
+    prm = pylbm.BgkParams(omega, 0, 1, form=pylbm.FORM_REFERENCE_ORDER)
     bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=pylbm.EDGE_SPECULAR,
                   col_hi=pylbm.EDGE_SPECULAR, uw_r=u_in)
     n = 1 + D * n_blocks
@@ -436,7 +438,7 @@ def test_ring_ibm_block_wrappers_on_a_self_ring(lib, oracle):
     X, Y, R, D = 384, 96, 128, 5
     omega, u_in = 1.0 / 0.55, 0.05
     x, y = circle(R + 64.3, Y / 2 + 0.21, 10.0)
-    prm = pylbm.BgkParams(omega, 0, 1)
+    prm = pylbm.BgkParams(omega, 0, 1, form=pylbm.FORM_REFERENCE_ORDER)
     bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=pylbm.EDGE_SPECULAR,
                   col_hi=pylbm.EDGE_SPECULAR, uw_r=u_in)
     u0 = np.zeros((R, Y, 2)); u0[..., 0] = u_in

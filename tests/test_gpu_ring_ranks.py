@@ -194,7 +194,7 @@ def test_ibm_blocks_across_processes_equal_one_block(lib, oracle, tmp_path, n, c
     x, y = circle(cx, Y / 2 + 0.21, radius)
     u0 = np.zeros((X, Y, 2)); u0[..., 0] = u_in
     f0 = oracle.incomp_equilibrium(u0, np.ones((X, Y)))
-    prm = pylbm.BgkParams(omega, 0, 1)
+    prm = pylbm.BgkParams(omega, 0, 1, form=pylbm.FORM_REFERENCE_ORDER)
     edge = pylbm.EDGE_SPECULAR if cols == "specular" else pylbm.EDGE_PERIODIC
     bc = pylbm.Bc(row_lo=pylbm.EDGE_ABB_VELOCITY, row_hi=pylbm.EDGE_ABB_VELOCITY, col_lo=edge, col_hi=edge, uw_r=u_in)
     sv = pylbm.Solver(lib, pylbm.MODEL_BGK, X, Y, prm, bc=bc)
