@@ -301,6 +301,9 @@ static int solver_ibm_block(lbm_solver* sv, int D) {
       LBM_CHECK_HIP(hipStreamWaitEvent(far, sv->ev_far_fork, 0));
       if (one_launch) rc = ibm_gate(sv->ibm, far);
       else rc = LBM_OK;
+      // (round 4, measured and not kept: the window as PERSISTENT waves that leave 32 .. 256 wave slots of the card free for
+      // the chain from its first cycle to its last -- 143 - 150 k MLUPS against 148.5 / 149.3 k with every slot taken, and
+      // 115 - 118 k against 124 - 128 k in the reference order: the chain is not waiting for slots.  profiles/r04_ibm_reserve.txt)
       if (!rc) rc = lbm_bgk_stream_collide_xn(dst, src, &sv->g, &sv->bc, &sv->bgk, D, 0, R, far);
       if (rc) return rc;
       LBM_CHECK_HIP(hipEventRecord(sv->ev_far_join, far));

@@ -397,6 +397,15 @@ __global__ __launch_bounds__(TR* TC, WAVES) void k_cg_fused(
                                            row_begin, row_end, xcd_swizzle, rect, (int)blockIdx.x, (int)gridDim.x);
 }
 
+// f(integral_constant<0>) ... f(integral_constant<N - 1>), in that order (C++17: no templated lambdas)
+template <int N, class F>
+__device__ __forceinline__ void cg_static_for(F&& f) {
+  if constexpr (N > 0) {
+    cg_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 // ---- the tile kernel with SEVERAL NODES PER THREAD (round 4) ----------------------------------------------------------
 // Same structure as k_cg_fused MODE 1 (one barrier, independent workgroups), larger tile: a workgroup of NT threads covers
 // TR x TC nodes, NPT = TR TC / NT per thread (node n = thread + k NT, so a wave still reads whole rows), which cuts what
@@ -467,48 +476,56 @@ __global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
   const int r_base = ra + tile_r * TR, c_base = ca + tile_c * TC;
   const int tr0 = threadIdx.x / TC, tc = threadIdx.x % TC;
 
+  // Phase 2 collides the thread's nodes in the order j = 0 .. NPT - 1; node j is node kj[j] of the tile pass order.  PARK: j = 0
+  // waits in registers (ft[0]), j >= 1 in LDS (s_park[j - 1]); otherwise all wait in registers (ft[j]).
   double ft[PARK ? 1 : NPT][Q], rr[NPT], rb[NPT];
-#pragma unroll
-  for (int k = NPT - 1; k >= 0; --k) {  // node 0 last: it stays in registers
+  int kj[NPT];
+  auto own = [&](int k, auto jc) {  // gather + reduce node k; it becomes phase 2's node j
+    constexpr int j = decltype(jc)::value;
     const int tr = tr0 + k * RPP;
     double fk[Q];
     const CgNode me = cg_node<true>(fk, in_r, in_b, g, Bc{}, cf, r_base + tr, c_base + tc);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      if (PARK && k > 0) s_park[k - 1][q][threadIdx.x] = fk[q];
-      else ft[PARK ? 0 : k][q] = fk[q];
+      if constexpr (PARK && j > 0) s_park[j - 1][q][threadIdx.x] = fk[q];
+      else ft[PARK ? 0 : j][q] = fk[q];
     }
-    rr[k] = me.rr;
-    rb[k] = me.rb;
+    rr[j] = me.rr;
+    rb[j] = me.rb;
+    kj[j] = k;
     s_psi[tr + 2][tc + 2] = me.psi;
     s_qx[tr + 2][tc + 2] = me.qx;
     s_qy[tr + 2][tc + 2] = me.qy;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  constexpr int NH = LR * LC - TR * TC;
-  for (int i = threadIdx.x; i < NH; i += NT) {  // the +-2 ring: two rows above, two below, then 2 + 2 columns beside each row
-    int lr, lc;
-    if (i < 2 * LC) {
-      lr = i / LC;
-      lc = i % LC;
-    } else if (i < 4 * LC) {
-      lr = TR + 2 + (i - 2 * LC) / LC;
-      lc = (i - 2 * LC) % LC;
-    } else {
-      const int j = i - 4 * LC;
-      lr = 2 + (j >> 2);
-      lc = (j & 3) < 2 ? (j & 3) : TC + (j & 3);
-    }
+  };
+  auto ring_node = [&](int lr, int lc) {
     double tmp[Q];
     const CgNode nb = cg_node<true>(tmp, in_r, in_b, g, Bc{}, cf, r_base + lr - 2, c_base + lc - 2);
     s_psi[lr][lc] = nb.psi;
     s_qx[lr][lc] = nb.qx;
     s_qy[lr][lc] = nb.qy;
+  };
+  // (round 4, measured and not kept: tile rows of even index read top to bottom, odd ones bottom to top, so that vertically
+  // adjacent tiles request the six rows they share at the same phase of their lives -- 16.44 - 16.59 k MLUPS against 16.61 - 16.72 k
+  // for the plain order over six patch orders on one box, profiles/r04_cg_alt_sweep_ab.txt)
+  {
+    // plain order: the last pass first, pass 0 last (it is the one that stays in registers), then the ring
+    cg_static_for<NPT>([&](auto kc) {
+      constexpr int k = NPT - 1 - decltype(kc)::value;
+      own(k, std::integral_constant<int, k>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // the +-2 ring, ONE slot per thread (336 of the 512 threads at 16 x 64): two rows above, two below, then 2 + 2 columns beside each row
+    constexpr int NH = LR * LC - TR * TC;
+    for (int i = threadIdx.x; i < NH; i += NT) {
+      if (i < 2 * LC) ring_node(i / LC, i % LC);
+      else if (i < 4 * LC) ring_node(TR + 2 + (i - 2 * LC) / LC, (i - 2 * LC) % LC);
+      else ring_node(2 + ((i - 4 * LC) >> 2), ((i - 4 * LC) & 3) < 2 ? ((i - 4 * LC) & 3) : TC + ((i - 4 * LC) & 3));
+    }
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NPT; ++k) {
-    int tr = tr0 + k * RPP;
+  for (int j = 0; j < NPT; ++j) {
+    int tr = tr0 + kj[j] * RPP;
     // opaque per node: otherwise the 18 store addresses of the later nodes are derived from the first node's and wait
     // in registers (scratch at 128) through its collision
     asm volatile("" : "+v"(tr));
@@ -518,10 +535,10 @@ __global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
     asm volatile("" : "+s"(cfk.Gr), "+s"(cfk.Gc));
     double fk[Q];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) fk[q] = (PARK && k > 0) ? s_park[k > 0 ? k - 1 : 0][q][threadIdx.x] : ft[PARK ? 0 : k][q];
+    for (int q = 0; q < Q; ++q) fk[q] = (PARK && j > 0) ? s_park[j > 0 ? j - 1 : 0][q][threadIdx.x] : ft[PARK ? 0 : j][q];
     CgNode me;  // == cg_node's expressions on the held sums
-    me.rr = rr[k];
-    me.rb = rb[k];
+    me.rr = rr[j];
+    me.rb = rb[j];
     const double jx = ((fk[1] - fk[3]) + (fk[5] - fk[6])) + (fk[8] - fk[7]);
     const double jy = ((fk[2] - fk[4]) + (fk[5] - fk[8])) + (fk[6] - fk[7]);
     me.irt = 1.0 / (me.rr + me.rb);
@@ -533,7 +550,7 @@ __global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
     const double dxqx = cg_ddrow<LDC>(s_qx, tr, tc), dyqy = cg_ddcol<LDC>(s_qy, tr, tc);
     cg_collide_store<WITH_FIELDS>(fk, me, gx, gy, dxqx, dyqy, cfk, g, mi, r_base + tr, c_base + tc, pn_r, pn_b,
                                   rho_r_out, rho_b_out, u_out, psi_out, snu_out);
-    if (k + 1 < NPT) __builtin_amdgcn_sched_barrier(0);
+    if (j + 1 < NPT) __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -641,17 +641,15 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
     }
     // uniform row base (scalar registers) + this lane's 32-bit byte offset: the loads take the saddr form and no
     // 64-bit vector address arithmetic (one v_lshl_add_u64 per access before; the KBC window is VALU-bound)
-    // LDSR (the VALU-bound KBC window): the three byte offsets are made opaque per iteration -- otherwise the compiler
-    // folds them into 18 loop-invariant per-lane 64-bit pointers (36 VGPRs) and spends one v_lshl_add_u64 per access
-    // adding the row offset; opaque, every access is `global_load v, v_off32, s[row base]` with no VALU work at all
-    unsigned co[3] = {(unsigned)cols[0] * 8u, (unsigned)cols[1] * 8u, (unsigned)cols[2] * 8u};
-    if constexpr (LDSR) asm volatile("" : "+v"(co[0]), "+v"(co[1]), "+v"(co[2]));
+    // (round 4, measured and NOT kept: for the LDS-ring window the 18 + 9 accesses of an iteration were forced onto the saddr
+    // form -- row base as an opaque scalar pair, 32-bit lane offset -- which takes 55 v_lshl_add_u64 out of the 3-iteration
+    // body (2288 -> 2233 VALU instructions, 281 instead of 287 lane-ops per update) and puts 250 scalar instructions in;
+    // KBC 4096^2 on one box, alternating: 70.0 / 70.1 / 70.2 / 71.9 k before, 69.0 / 69.1 / 69.1 / 69.0 k after.
+    // profiles/r04_kbc_saddr_ab.txt)
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      long ro = q * g.plane + g.at(rr[icx(q) + 1], 0);
-      if constexpr (LDSR) asm volatile("" : "+s"(ro));  // the plane's row offset stays a scalar pair (scalar adds per access, no VALU)
-      const char* rowp = reinterpret_cast<const char*>(po + ro);
-      nxt[q] = *reinterpret_cast<const double*>(rowp + co[icy(q) + 1]);
+      const char* rowp = reinterpret_cast<const char*>(po + q * g.plane + g.at(rr[icx(q) + 1], 0));
+      nxt[q] = *reinterpret_cast<const double*>(rowp + (unsigned)cols[icy(q) + 1] * 8u);
     }
   }
   // ---- level 1 ---------------------------------------------------------------------------------
@@ -736,23 +734,9 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
   const int rD = rbase + i - (D - 1);  // level D's row = level 1's row - (D-1)
   if (lane_ok && rD >= R0 && rD < R1) {
     const long o = g.at(rD, 0);
-    unsigned so = (unsigned)c_out * 8u;
-    if constexpr (LDSR) asm volatile("" : "+v"(so));
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
-      if constexpr (LDSR) {
-        // the plane's row base as an opaque SCALAR pair + this lane's 32-bit byte offset: `global_store v_off, v[data], s[base]`
-        // (left to itself the compiler adds the lane offset to pn first -- one per-lane 64-bit pointer -- and then pays a
-        // v_lshl_add_u64 per plane)
-        unsigned long base = reinterpret_cast<unsigned long>(pn) + (unsigned long)((q * g.plane + o) * 8);
-        asm volatile("" : "+s"(base));
-        typedef __attribute__((address_space(1))) double gdouble;
-        gdouble* gp = reinterpret_cast<gdouble*>(base + so);
-        if (NT_STORE) __builtin_nontemporal_store(f[q], gp);
-        else *gp = f[q];
-        continue;
-      }
-      double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(pn + q * g.plane + o) + so);
+      double* dst = reinterpret_cast<double*>(reinterpret_cast<char*>(pn + q * g.plane + o) + (unsigned)c_out * 8u);
       if (NT_STORE) __builtin_nontemporal_store(f[q], dst);
       else *dst = f[q];
     }

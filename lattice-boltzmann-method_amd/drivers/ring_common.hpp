@@ -121,7 +121,10 @@ inline void share_unique_id(unsigned char (&id)[128], int rank, int world, const
 // driver returns 4 instead of printing a rate (its peers are ended by the launcher)
 inline int ring_failed(lbm_ring* ring, const char* driver, int rank) {
   if (lbm_ring_status(ring) == 0) return 0;
-  std::printf("{\"driver\": \"%s\", \"rank\": %d, \"error\": \"%s\"}\n", driver, rank, lbm_last_error_string());
+  std::string msg = lbm_last_error_string();
+  for (char& ch : msg)
+    if (ch == '"' || ch == '\\') ch = '\'';  // (the message goes into a JSON string)
+  std::printf("{\"driver\": \"%s\", \"rank\": %d, \"error\": \"%s\"}\n", driver, rank, msg.c_str());
   std::fflush(stdout);
   return 4;
 }

@@ -207,6 +207,21 @@ def test_ring_drivers_with_three_real_ranks_on_one_gpu(tmp_path, driver, args):
     assert line["check"] == "bitwise equal to one block" and line["n_gpus"] == 3
 
 
+def test_ring_driver_reports_a_neighbour_that_left(tmp_path):
+    """the C++ ring hosts read lbm_ring_status after their timed launches.  `--desert 1`: rank 1 joins the ring and
+    leaves; rank 0's bounded waits give up (1.5 s here), its lattices and timings are void -- it says so as JSON and the
+    driver returns 4 instead of a rate"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_box")
+    env = dict(os.environ, LBM_TUNE="ring_ipc_timeout_ms=1500")
+    r = subprocess.run([exe, "--spawn", "2", "--transport", "ipc", "--one-gpu", "1", "--desert", "1", "--rows", "96", "--cols", "160",
+                        "--steps", "3", "--warmup", "1", "--depth", "5", "--period", "2", "--edge-rows", "16", "--id-file", str(tmp_path / "id")],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 4, (r.returncode, r.stdout[-1000:], r.stderr[-1000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["rank"] == 0 and "never delivered" in line["error"] and "mlups" not in line
+
+
 def test_slab_ring_cylinder_driver(tmp_path):
     """C++ host of config 5 over slabs (drivers/slab_ring_cylinder.cpp on lbm_ring_ibm_start /
     lbm_ring_bgk_block_ibm): 5-step blocks, the band around the ROI in a compact replica beside the far
