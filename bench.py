@@ -746,7 +746,7 @@ class Secondary:
         elif which == "cg":     # config 4: mrtcg_rayleigh_taylor.cpp:182-210 (init_rho_cosine) at 8192 x 2048
             R, C = 8192, 2048
             self.unit = 1
-            self.kernel = ("k_cg_tile_mn<16,64,512,4,parked> (inner rectangle: 16x64 tiles, 2 nodes per thread, patches of 8x2 tiles per XCD) "
+            self.kernel = ("k_cg_tile_mn<16,64,512,4,parked> (inner rectangle: 16x64 tiles, 2 nodes per thread, patches of 4x2 tiles per XCD) "
                            "+ k_cg_fused<16,32,4,.,2> on the frame")
             self.bytes_per_update, self.config = 288.0, "mrtcg_rayleigh_taylor 8192x2048 colour-gradient two-phase MRT, gamma3 parameters"
             prm = pylbm.cg_params()

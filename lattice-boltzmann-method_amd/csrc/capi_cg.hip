@@ -166,9 +166,11 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
   const int sw4 = n_btr ? 0 : tuning("cg_strip2", 0);
   if (n_btr) {  // k_cg_tile_mn: big tiles, several nodes per thread
     const int ra = row_begin + rc.ir0 * TR, ca = rc.ic0 * TC, nt = n_btr * n_btc;
-    // patches of 8 x 2 tiles per XCD (100 PR + PC): ring rows and ring columns inside a patch are hits of one L2 (2: pairs of
-    // column neighbours as k_cg_fused; the tall patches add 3 - 4 % on top, profiles/r04_cg_big_sweep.txt)
-    const int bx = tuning("cg_big_xcd", 802);
+    // patches of 4 x 2 tiles per XCD (100 PR + PC): ring rows and ring columns inside a patch are hits of one L2.  Larger
+    // patches read less and less (4.09 GB per step with pairs of column neighbours, 3.99 with 4 x 2, 3.90 with 8 x 2, 3.73 with
+    // 8 x 4) but the rate the memory system delivers falls with them on some boxes: 4 x 2 is the order that is never slower
+    // than the pairs (+3.6 %, +0.4 %, +0.2 % on three boxes; 8 x 2: +4.7 %, -0.3 %, -2.9 %), profiles/r04_cg_order_pmc.txt
+    const int bx = tuning("cg_big_xcd", 402);
     g_last_inner_form = 100 + shape;
 #define LBM_CG_BIG(BR, BC, BT, BM, BP)                                                                               \
     if (psi) LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, true>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx); \
