@@ -735,7 +735,7 @@ class Secondary:
         # other (virtual and physical) addresses -- to tell a placement effect from a kernel effect
         self._placement = torch.empty(int(os.environ.get("LBM_BENCH_PREALLOC_MB", "0")) << 20, dtype=torch.uint8, device=dev)
         if which == "kbc":      # config 3: ulbm_double_shear_flow.cpp:42-63 at 4096^2 (s2 = omega, nu = 1.70766666e-4)
-            R = C = 4096
+            R, C = 4096, int(os.environ.get("LBM_BENCH_KBC_COLS", "4096"))   # (other widths: a probe of row-stride effects)
             self.unit = int(lib.raw.lbm_get_tuning(b"kbc_depth")) or 3
             self.kernel = f"k_stream_collide_sw<KbcFastModel,{self.unit},2,nt>"
             self.bytes_per_update, self.config = 144.0, "ulbm_double_shear_flow 4096x4096 KBC (entropic MRT), periodic"
@@ -744,7 +744,7 @@ class Secondary:
             lib.solver_set_f_soa_dev(self.sv.h, _ptr(f))
             self.step = lambda n: self.sv.step(n)
         elif which == "cg":     # config 4: mrtcg_rayleigh_taylor.cpp:182-210 (init_rho_cosine) at 8192 x 2048
-            R, C = 8192, 2048
+            R, C = 8192, int(os.environ.get("LBM_BENCH_CG_COLS", "2048"))   # (other widths: a probe of row-stride effects)
             self.unit = 1
             self.kernel = ("k_cg_tile_mn<16,64,512,4,parked> (inner rectangle: 16x64 tiles, 2 nodes per thread, patches of 4x2 tiles per XCD) "
                            "+ k_cg_fused<16,32,4,.,2> on the frame")

@@ -75,6 +75,12 @@ int lbm_aos_to_soa_ex(double* soa, const double* aos, int R, int C, int Q, long 
                       lbm_stream_t s);
 int lbm_soa_to_aos_ex(double* aos, const double* soa, int R, int C, int Q, long long plane_stride,
                       lbm_stream_t s);
+/* the same with a row pitch on the SoA side (lbm_geom.row_pitch; 0 = dense): node (r, c) of plane q at
+ * q * plane_stride + r * row_pitch + c */
+int lbm_aos_to_soa_pitched(double* soa, const double* aos, int R, int C, int Q,
+                           long long plane_stride, int row_pitch, lbm_stream_t s);
+int lbm_soa_to_aos_pitched(double* aos, const double* soa, int R, int C, int Q,
+                           long long plane_stride, int row_pitch, lbm_stream_t s);
 /* padding (doubles) the engine recommends between population planes of an R x C lattice */
 long long lbm_default_plane_pad(int R, int C);
 
@@ -99,9 +105,18 @@ typedef struct lbm_geom {
                 neighbouring slabs (1: one step per launch; n: n-step launches; 3: the
                 colour-gradient step) */
   long long plane_stride; /* doubles between consecutive population planes; 0 = dense
-                             ((R + 2*ghost) * C).  Padding it off a power of two spreads the 18
+                             ((R + 2*ghost) * row pitch).  Padding it off a power of two spreads the 18
                              concurrent streams of the fused step over the HBM channels. */
+  int row_pitch;          /* doubles between consecutive rows of a plane; 0 = dense (C).  Node (r, c) of plane q
+                             lives at q * plane_stride + (r + ghost) * row_pitch + c ("row padding, hidden behind the
+                             ABI"): with C a power of two, rows a power of two apart land on the same
+                             L2 sets and DRAM pages -- the solver contexts pad their own lattices (lbm_default_row_pitch).
+                             Must be even and >= C.  Entry points that take a lattice honour it; buffers of
+                             macroscopic fields (rho, u, psi ...) and AoS arrays are always dense. */
 } lbm_geom;
+/* the row pitch the solver contexts use for a lattice of C columns: C + 64 doubles where C * 8 bytes is a multiple
+ * of 4 KiB and C >= 1024 (tuning "row_pad": that many doubles instead of 64, 0 = never), else C */
+int lbm_default_row_pitch(int C);
 
 /* What the reference drivers do to the populations a node cannot receive from inside the
  * domain.  Every mode restates one driver fix-up (all applied post-streaming, reading the

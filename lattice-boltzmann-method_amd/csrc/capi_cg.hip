@@ -163,7 +163,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     LBM_CHECK_LAUNCH();
   }
   if (part == 1) return LBM_OK;
-  const int sw4 = n_btr ? 0 : tuning("cg_strip2", 0);
+  const int sw4 = (n_btr || (g.P != g.C && tuning("cg_strip2", 0) < 41)) ? 0 : tuning("cg_strip2", 0);  // (the strip forms of the experiments build know dense rows only)
   if (n_btr) {  // k_cg_tile_mn: big tiles, several nodes per thread
     const int ra = row_begin + rc.ir0 * TR, ca = rc.ic0 * TC, nt = n_btr * n_btc;
     // patches of 4 x 2 tiles per XCD (100 PR + PC): ring rows and ring columns inside a patch are hits of one L2.  Larger
@@ -426,7 +426,7 @@ static int cg_step_fused(double* pn_r, double* pn_b, const double* p_r, const do
   const MacroIdx mi = make_macro_idx(gg);
   hipStream_t st = as_stream(s);
 #ifdef LBM_EXPERIMENTS
-  switch (tuning("cg_strip", 0)) {  // column-strip sliding window (opt-in: slower as written, cg_fused.hpp), waves per workgroup
+  switch (gg.P != gg.C ? 0 : tuning("cg_strip", 0)) {  // column-strip sliding window (opt-in: slower as written, cg_fused.hpp), waves per workgroup
     case 0: break;
     case 2: return launch_cg_strip_t<2>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
     case 4: return launch_cg_strip_t<4>(pn_r, pn_b, p_r, p_b, gg, bb, cf, rho_r, rho_b, u, psi, snu, mi, row_begin, row_end, st);
@@ -512,7 +512,11 @@ int lbm_cg_solver_create(lbm_cg_solver** out, const lbm_geom* g, const lbm_bc* b
   for (int b = 0; b < 2; ++b)
     for (int k = 0; k < 2; ++k) sv->rband[b][k] = sv->cband[b][k] = nullptr;
   const size_t n = (size_t)g->R * g->C;
-  sv->g.plane_stride = (long long)n + lbm_default_plane_pad(g->R, g->C);
+  // the solver's own lattices: rows padded off a power-of-two stride (lbm_default_row_pitch), planes likewise.  Everything
+  // that reads or writes them takes &sv->g; the macroscopic fields and the host-side AoS arrays stay dense.
+  const int pitch = lbm_default_row_pitch(g->C);
+  sv->g.row_pitch = pitch > g->C ? pitch : 0;
+  sv->g.plane_stride = (long long)g->R * pitch + lbm_default_plane_pad(g->R, pitch);
   const size_t lat_bytes = (size_t)sv->g.plane_stride * 9 * sizeof(double);
   double** all[] = {&sv->lat[0][0], &sv->lat[0][1], &sv->lat[1][0], &sv->lat[1][1], &sv->rho_r,
                     &sv->rho_b, &sv->u, &sv->psi, &sv->snu, &sv->stage};
@@ -557,7 +561,7 @@ int lbm_cg_solver_set_state(lbm_cg_solver* sv, const double* f_r, const double* 
   const double* fs[2] = {f_r, f_b};
   for (int k = 0; k < 2; ++k) {
     LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, fs[k], n * 72, hipMemcpyHostToDevice, sv->st));
-    int rc = lbm_aos_to_soa_ex(sv->lat[sv->cur][k], sv->stage, R, C, 9, sv->g.plane_stride, sv->st);
+    int rc = lbm_aos_to_soa_pitched(sv->lat[sv->cur][k], sv->stage, R, C, 9, sv->g.plane_stride, sv->g.row_pitch, sv->st);
     if (rc) return rc;
   }
   LBM_CHECK_HIP(hipMemcpyAsync(sv->rho_r, rho_r, n * 8, hipMemcpyHostToDevice, sv->st));
@@ -584,7 +588,7 @@ static bool cg_two_step_applies(const lbm_cg_solver* sv) {
   const lbm_bc& b = sv->bc;
   const bool walls = b.row_lo == d.row_lo && b.row_hi == d.row_hi && b.col_lo == d.col_lo && b.col_hi == d.col_hi && !b.pressure_rows;
   const long long plane = sv->g.plane_stride;
-  return walls && sv->g.ghost == 0 && sv->g.C % 16 == 0 && plane % 16 == 0 && sv->g.R >= 2 * kCgX2HB + 64 && sv->g.C >= 2 * kCgX2WB + 256;
+  return walls && sv->g.row_pitch == 0 && sv->g.ghost == 0 && sv->g.C % 16 == 0 && plane % 16 == 0 && sv->g.R >= 2 * kCgX2HB + 64 && sv->g.C >= 2 * kCgX2WB + 256;
 }
 
 static int cg_two_step_prepare(lbm_cg_solver* sv) {
@@ -731,7 +735,7 @@ int lbm_cg_solver_get_state(lbm_cg_solver* sv, double* f_r, double* f_b, double*
       if (rc) return rc;
       src = scratch;
     }
-    int rc = lbm_soa_to_aos_ex(sv->stage, src, R, C, 9, sv->g.plane_stride, sv->st);
+    int rc = lbm_soa_to_aos_pitched(sv->stage, src, R, C, 9, sv->g.plane_stride, sv->g.row_pitch, sv->st);
     if (rc) return rc;
     LBM_CHECK_HIP(hipMemcpyAsync(fo[k], sv->stage, n * 72, hipMemcpyDeviceToHost, sv->st));
     LBM_CHECK_HIP(hipStreamSynchronize(sv->st));

@@ -87,20 +87,22 @@ int tuning(const char* key, int dflt) {
 template <bool TO_SOA>
 __global__ __launch_bounds__(256) void k_layout(double* __restrict__ dst,
                                                 const double* __restrict__ src, long n, int Qn,
-                                                long ps /* SoA plane stride */) {
+                                                long ps /* SoA plane stride */, int C, int P /* SoA row pitch (== C: dense) */) {
   extern __shared__ double tile[];  // [256 * Qn]
   for (long base = (long)blockIdx.x * 256; base < n; base += (long)gridDim.x * 256) {
     const int cnt = (int)((n - base) < 256 ? (n - base) : 256);
+    const long i = base + threadIdx.x;                       // this thread's node, row-major over [R][C]
+    const long o = P == C ? i : (i / C) * (long)P + i % C;   // ... and where it lives in a plane
     if (TO_SOA) {
-      for (int i = threadIdx.x; i < cnt * Qn; i += 256) tile[i] = src[base * Qn + i];
+      for (int k = threadIdx.x; k < cnt * Qn; k += 256) tile[k] = src[base * Qn + k];
       __syncthreads();
       if ((int)threadIdx.x < cnt)
-        for (int q = 0; q < Qn; ++q) dst[(long)q * ps + base + threadIdx.x] = tile[threadIdx.x * Qn + q];
+        for (int q = 0; q < Qn; ++q) dst[(long)q * ps + o] = tile[threadIdx.x * Qn + q];
     } else {
       if ((int)threadIdx.x < cnt)
-        for (int q = 0; q < Qn; ++q) tile[threadIdx.x * Qn + q] = src[(long)q * ps + base + threadIdx.x];
+        for (int q = 0; q < Qn; ++q) tile[threadIdx.x * Qn + q] = src[(long)q * ps + o];
       __syncthreads();
-      for (int i = threadIdx.x; i < cnt * Qn; i += 256) dst[base * Qn + i] = tile[i];
+      for (int k = threadIdx.x; k < cnt * Qn; k += 256) dst[base * Qn + k] = tile[k];
     }
     __syncthreads();
   }
@@ -489,29 +491,47 @@ static int check_shape(const char* fn, int R, int C) {
     if (rc_) return rc_;                       \
   } while (0)
 
-int lbm_aos_to_soa_ex(double* soa, const double* aos, int R, int C, int Qn,
-                      long long plane_stride, lbm_stream_t s) {
+int lbm_aos_to_soa_pitched(double* soa, const double* aos, int R, int C, int Qn,
+                           long long plane_stride, int row_pitch, lbm_stream_t s) {
   SHAPE_OR_RETURN("lbm_aos_to_soa");
   LBM_REQUIRE(soa && aos && Qn >= 1 && Qn <= 16, "lbm_aos_to_soa: bad pointer or Q=%d", Qn);
+  const int P = row_pitch > 0 ? row_pitch : C;
   const long n = (long)R * C;
-  LBM_REQUIRE(plane_stride == 0 || plane_stride >= n, "lbm_aos_to_soa: plane_stride too small");
+  LBM_REQUIRE(P >= C && (plane_stride == 0 || plane_stride >= (long long)R * P), "lbm_aos_to_soa: row_pitch / plane_stride too small");
   LBM_KLAUNCH(k_layout<true>, dim3(capped_grid((n + 255) / 256)), dim3(256),
               256 * Qn * sizeof(double), as_stream(s), soa, aos, n, Qn,
-              plane_stride ? (long)plane_stride : n);
+              plane_stride ? (long)plane_stride : (long)R * P, C, P);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
 }
-int lbm_soa_to_aos_ex(double* aos, const double* soa, int R, int C, int Qn,
-                      long long plane_stride, lbm_stream_t s) {
+int lbm_soa_to_aos_pitched(double* aos, const double* soa, int R, int C, int Qn,
+                           long long plane_stride, int row_pitch, lbm_stream_t s) {
   SHAPE_OR_RETURN("lbm_soa_to_aos");
   LBM_REQUIRE(soa && aos && Qn >= 1 && Qn <= 16, "lbm_soa_to_aos: bad pointer or Q=%d", Qn);
+  const int P = row_pitch > 0 ? row_pitch : C;
   const long n = (long)R * C;
-  LBM_REQUIRE(plane_stride == 0 || plane_stride >= n, "lbm_soa_to_aos: plane_stride too small");
+  LBM_REQUIRE(P >= C && (plane_stride == 0 || plane_stride >= (long long)R * P), "lbm_soa_to_aos: row_pitch / plane_stride too small");
   LBM_KLAUNCH(k_layout<false>, dim3(capped_grid((n + 255) / 256)), dim3(256),
               256 * Qn * sizeof(double), as_stream(s), aos, soa, n, Qn,
-              plane_stride ? (long)plane_stride : n);
+              plane_stride ? (long)plane_stride : (long)R * P, C, P);
   LBM_CHECK_LAUNCH();
   return LBM_OK;
+}
+int lbm_aos_to_soa_ex(double* soa, const double* aos, int R, int C, int Qn,
+                      long long plane_stride, lbm_stream_t s) {
+  return lbm_aos_to_soa_pitched(soa, aos, R, C, Qn, plane_stride, 0, s);
+}
+int lbm_soa_to_aos_ex(double* aos, const double* soa, int R, int C, int Qn,
+                      long long plane_stride, lbm_stream_t s) {
+  return lbm_soa_to_aos_pitched(aos, soa, R, C, Qn, plane_stride, 0, s);
+}
+int lbm_default_row_pitch(int C) {
+  // rows a power of two apart (C * 8 bytes a multiple of 4 KiB) land on the same L2 sets and DRAM pages: the two-phase tile
+  // kernel gains 4 % at 2112 or 1984 columns over 2048, the KBC window 3 % (profiles/r04_row_stride_probe.txt); the BGK
+  // window nothing.  64 doubles (512 bytes) keep every row 128-byte aligned.
+  const int pad = tuning("row_pad", 64);
+  if (pad <= 0 || C < 1024 || ((long)C * 8) % 4096 != 0) return C;
+  return C + (pad + 1) / 2 * 2;
 }
 int lbm_aos_to_soa(double* soa, const double* aos, int R, int C, int Qn, lbm_stream_t s) {
   return lbm_aos_to_soa_ex(soa, aos, R, C, Qn, 0, s);

@@ -146,8 +146,10 @@ extern "C" {
 int lbm_links_create(lbm_links** out, int n_lattices, const lbm_geom* geoms) {
   LBM_REQUIRE(out && geoms && n_lattices >= 1 && n_lattices <= kMaxLinkLattices,
               "lbm_links_create: 1..%d lattices", kMaxLinkLattices);
-  for (int i = 0; i < n_lattices; ++i)
+  for (int i = 0; i < n_lattices; ++i) {
     LBM_REQUIRE(geoms[i].R > 0 && geoms[i].C > 0 && geoms[i].ghost >= 0, "lbm_links_create: bad geometry %d", i);
+    LBM_REQUIRE(geoms[i].row_pitch == 0 || geoms[i].row_pitch == geoms[i].C, "lbm_links_create: dense rows only (lattice %d)", i);
+  }
   lbm_links* t = new (std::nothrow) lbm_links();
   LBM_REQUIRE(t, "lbm_links_create: out of host memory");
   t->geoms.assign(geoms, geoms + n_lattices);

@@ -77,6 +77,7 @@ int lbm_slab_ibm_create(lbm_slab_ibm** out, const lbm_geom* slab, int slab_row0,
                         const lbm_bc* bc_global, const lbm_bgk_params* prm, int depth, const double* x,
                         const double* y, int n_markers, int m_max, double guo_a, double guo_b) {
   LBM_REQUIRE(out && slab && bc_global && prm && x && y && n_markers > 0, "lbm_slab_ibm_create: bad argument");
+  LBM_REQUIRE(slab->row_pitch == 0 || slab->row_pitch == slab->C, "lbm_slab_ibm_create: dense rows only (row_pitch = %d)", slab->row_pitch);
   const int R = slab->R, C = slab->C, D = depth;
   LBM_REQUIRE(D >= 2 && D <= 5, "lbm_slab_ibm_create: depth=%d (supported: 2..5)", D);
   LBM_REQUIRE(slab->ghost >= D, "lbm_slab_ibm_create: slab has %d ghost rows, %d-step blocks need %d", slab->ghost, D, D);

@@ -86,6 +86,7 @@ int lbm_slab_pressure_create_kbc(lbm_slab_pressure** out, const lbm_geom* slab, 
 static int slab_pressure_create(lbm_slab_pressure** out, const lbm_geom* slab, int slab_row0, int rows_global,
                                 const lbm_bc* bc_global, const lbm_bgk_params* prm, const lbm_kbc_params* kprm, int depth) {
   LBM_REQUIRE(out && slab && bc_global, "lbm_slab_pressure_create: NULL argument");
+  LBM_REQUIRE(slab->row_pitch == 0 || slab->row_pitch == slab->C, "lbm_slab_pressure_create: dense rows only (row_pitch = %d)", slab->row_pitch);
   const int R = slab->R, C = slab->C, D = depth;
   LBM_REQUIRE(D >= 2 && D <= 5, "lbm_slab_pressure_create: depth=%d (supported: 2..5)", D);
   LBM_REQUIRE(slab->ghost >= D && R >= 6 * D + 8 && C >= 64, "lbm_slab_pressure_create: slab %dx%d with %d ghost rows too small for %d-step blocks", R, C, slab->ghost, D);

@@ -98,6 +98,7 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
   LBM_REQUIRE(out && g && params, "lbm_solver_create: NULL argument");
   LBM_REQUIRE(model == LBM_MODEL_BGK || model == LBM_MODEL_KBC, "lbm_solver_create: model=%d", model);
   LBM_REQUIRE(g->ghost == 0, "lbm_solver_create: single block only (ghost=0)");
+  LBM_REQUIRE(g->row_pitch == 0 || g->row_pitch == g->C, "lbm_solver_create: dense rows only (row_pitch = %d)", g->row_pitch);
   int rc = validate_geom_bc("lbm_solver_create", g, bc);
   if (rc) return rc;
   lbm_solver* sv = new (std::nothrow) lbm_solver();
@@ -119,7 +120,12 @@ int lbm_solver_create(lbm_solver** out, int model, const lbm_geom* g, const lbm_
   const size_t n = (size_t)g->R * g->C;
   // Population planes are padded off their natural (often power-of-two) stride: 18 streams at
   // the same offset modulo 2^k hit the same HBM channels (+9 % MLUPS at 8192^2).
-  sv->g.plane_stride = (long long)n + lbm_default_plane_pad(g->R, g->C);
+  // KBC solvers pad their ROWS too (lbm_default_row_pitch: +3 % at 4096 columns; the BGK window gains nothing and the
+  // BGK solver's immersed-boundary / checkpoint paths keep dense rows).  Everything that touches the lattices takes
+  // &sv->g or goes through solver_copy_planes below.
+  const int pitch = model == LBM_MODEL_KBC ? lbm_default_row_pitch(g->C) : g->C;
+  sv->g.row_pitch = pitch > g->C ? pitch : 0;
+  sv->g.plane_stride = (long long)g->R * pitch + lbm_default_plane_pad(g->R, pitch);
   const size_t lat_doubles = (size_t)sv->g.plane_stride * 9;
   sv->lat[0] = sv->lat[1] = sv->stage = sv->rho = sv->u = nullptr;
   hipError_t e = hipMalloc(&sv->lat[0], lat_doubles * sizeof(double));
@@ -188,9 +194,22 @@ int lbm_solver_set_moments_aos(lbm_solver* sv, const double* rho_host, const dou
   return LBM_OK;
 }
 
+// rows [row0, row0 + n_rows) of all 9 planes between the solver's (padded) lattice and a DENSE array of planes [9][rows_dense][C]
+// starting at its row `drow0` -- through the node-addressed copy kernel, so that neither side's strides matter
+static int solver_copy_planes(lbm_solver* sv, double* lattice, bool to_lattice, double* dense, long long dense_plane, int rows_dense,
+                              int drow0, int row0, int n_rows, hipStream_t st) {
+  const lbm_geom dg{rows_dense, sv->g.C, 0, dense_plane, 0};
+  if (to_lattice) return box_copy(lattice, sv->g, row0, 0, dense, dg, drow0, 0, n_rows, sv->g.C, st);
+  return box_copy(dense, dg, drow0, 0, lattice, sv->g, row0, 0, n_rows, sv->g.C, st);
+}
+
 int lbm_solver_set_f_soa_dev(lbm_solver* sv, const double* f_dev) {
   LBM_REQUIRE(sv && f_dev, "lbm_solver_set_f_soa_dev: NULL argument");
   const size_t plane_bytes = (size_t)sv->g.R * sv->g.C * sizeof(double);
+  if (sv->g.row_pitch) {
+    int rc = solver_copy_planes(sv, sv->lat[sv->cur], true, const_cast<double*>(f_dev), 0, sv->g.R, 0, 0, sv->g.R, sv->st);
+    if (rc) return rc;
+  } else
   LBM_CHECK_HIP(hipMemcpy2DAsync(sv->lat[sv->cur], (size_t)sv->g.plane_stride * sizeof(double), f_dev,
                                  plane_bytes, plane_bytes, 9, hipMemcpyDeviceToDevice, sv->st));
   sv->post = false;
@@ -203,7 +222,7 @@ int lbm_solver_set_f_aos(lbm_solver* sv, const double* f_host) {
   LBM_REQUIRE(sv && f_host, "lbm_solver_set_f_aos: NULL argument");
   const size_t bytes = (size_t)sv->g.R * sv->g.C * 9 * sizeof(double);
   LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, f_host, bytes, hipMemcpyHostToDevice, sv->st));
-  int rc = lbm_aos_to_soa_ex(sv->lat[sv->cur], sv->stage, sv->g.R, sv->g.C, 9, sv->g.plane_stride, sv->st);
+  int rc = lbm_aos_to_soa_pitched(sv->lat[sv->cur], sv->stage, sv->g.R, sv->g.C, 9, sv->g.plane_stride, sv->g.row_pitch, sv->st);
   if (rc) return rc;
   LBM_CHECK_HIP(hipStreamSynchronize(sv->st));  // f_host may be reused by the caller
   sv->post = false;
@@ -228,6 +247,7 @@ int lbm_solver_get_f_soa_dev(lbm_solver* sv, double* f_dev) {
   int rc = solver_f_adve(sv, &src);
   if (rc) return rc;
   const size_t plane_bytes = (size_t)sv->g.R * sv->g.C * sizeof(double);
+  if (sv->g.row_pitch) return solver_copy_planes(sv, const_cast<double*>(src), false, f_dev, 0, sv->g.R, 0, 0, sv->g.R, sv->st);
   LBM_CHECK_HIP(hipMemcpy2DAsync(f_dev, plane_bytes, src, (size_t)sv->g.plane_stride * sizeof(double),
                                  plane_bytes, 9, hipMemcpyDeviceToDevice, sv->st));
   return LBM_OK;
@@ -238,7 +258,7 @@ int lbm_solver_get_f_aos(lbm_solver* sv, double* f_host) {
   const double* src;
   int rc = solver_f_adve(sv, &src);
   if (rc) return rc;
-  rc = lbm_soa_to_aos_ex(sv->stage, src, sv->g.R, sv->g.C, 9, sv->g.plane_stride, sv->st);
+  rc = lbm_soa_to_aos_pitched(sv->stage, src, sv->g.R, sv->g.C, 9, sv->g.plane_stride, sv->g.row_pitch, sv->st);
   if (rc) return rc;
   const size_t bytes = (size_t)sv->g.R * sv->g.C * 9 * sizeof(double);
   LBM_CHECK_HIP(hipMemcpyAsync(f_host, sv->stage, bytes, hipMemcpyDeviceToHost, sv->st));
@@ -365,9 +385,15 @@ static int solver_pressure_block(lbm_solver* sv, int D) {
   LBM_CHECK_HIP(hipEventRecord(sv->ev_seam_fork, sv->st));
   LBM_CHECK_HIP(hipStreamWaitEvent(ss, sv->ev_seam_fork, 0));
   // rows [0, 2D) -> small rows [0, 2D); rows [R - 2D, R) -> small rows [2D, 4D)
+  if (sv->g.row_pitch) {  // padded rows: the node-addressed copy
+    int rcp = solver_copy_planes(sv, const_cast<double*>(src), false, sv->seam[0], sv->seam_plane, Rb, 0, 0, 2 * D, ss);
+    if (!rcp) rcp = solver_copy_planes(sv, const_cast<double*>(src), false, sv->seam[0], sv->seam_plane, Rb, 2 * D, R - 2 * D, 2 * D, ss);
+    if (rcp) return rcp;
+  } else {
   LBM_CHECK_HIP(hipMemcpy2DAsync(sv->seam[0], dpitch, src, spitch, half, 9, hipMemcpyDeviceToDevice, ss));
   LBM_CHECK_HIP(hipMemcpy2DAsync(sv->seam[0] + (size_t)2 * D * C, dpitch, src + (size_t)(R - 2 * D) * C, spitch, half, 9,
                                  hipMemcpyDeviceToDevice, ss));
+  }
   int cur = 0, rc = LBM_OK;
   for (int k = 0; k < D && !rc; ++k, cur ^= 1)
     rc = sv->model == LBM_MODEL_BGK
@@ -375,9 +401,15 @@ static int solver_pressure_block(lbm_solver* sv, int D) {
              : lbm_kbc_stream_collide(sv->seam[cur ^ 1], sv->seam[cur], &sg, &sv->bc, &sv->kbc, 0, Rb, nullptr, nullptr, ss);
   if (rc) return rc;
   const size_t part = (size_t)D * C * sizeof(double);
+  if (sv->g.row_pitch) {
+    int rcp = solver_copy_planes(sv, dst, true, sv->seam[cur], sv->seam_plane, Rb, 0, 0, D, ss);
+    if (!rcp) rcp = solver_copy_planes(sv, dst, true, sv->seam[cur], sv->seam_plane, Rb, 3 * D, R - D, D, ss);
+    if (rcp) return rcp;
+  } else {
   LBM_CHECK_HIP(hipMemcpy2DAsync(dst, spitch, sv->seam[cur], dpitch, part, 9, hipMemcpyDeviceToDevice, ss));
   LBM_CHECK_HIP(hipMemcpy2DAsync(dst + (size_t)(R - D) * C, spitch, sv->seam[cur] + (size_t)3 * D * C, dpitch, part, 9,
                                  hipMemcpyDeviceToDevice, ss));
+  }
   LBM_CHECK_HIP(hipEventRecord(sv->ev_seam_join, ss));
   // the far rows: plain multi-step window (walls on the columns included), no pressure rows
   lbm_bc far = sv->bc;
@@ -716,6 +748,11 @@ int lbm_solver_checkpoint_save(lbm_solver* sv, const char* path) {
   const size_t n = (size_t)sv->g.R * sv->g.C;
   std::vector<double> host(n * 9);
   const size_t plane_bytes = n * sizeof(double);
+  if (sv->g.row_pitch) {  // padded rows: through the dense staging buffer (the file always holds dense planes)
+    int rc = solver_copy_planes(sv, sv->lat[sv->cur], false, sv->stage, 0, sv->g.R, 0, 0, sv->g.R, sv->st);
+    if (rc) return rc;
+    LBM_CHECK_HIP(hipMemcpyAsync(host.data(), sv->stage, 9 * plane_bytes, hipMemcpyDeviceToHost, sv->st));
+  } else
   LBM_CHECK_HIP(hipMemcpy2DAsync(host.data(), plane_bytes, sv->lat[sv->cur],
                                  (size_t)sv->g.plane_stride * sizeof(double), plane_bytes, 9,
                                  hipMemcpyDeviceToHost, sv->st));
@@ -753,6 +790,11 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path) {
   std::fclose(f);
   LBM_REQUIRE(ok, "lbm_solver_checkpoint_load: %s is not a complete checkpoint", path);
   const size_t plane_bytes = n * sizeof(double);
+  if (sv->g.row_pitch) {
+    LBM_CHECK_HIP(hipMemcpyAsync(sv->stage, host.data(), 9 * plane_bytes, hipMemcpyHostToDevice, sv->st));
+    int rc = solver_copy_planes(sv, sv->lat[sv->cur], true, sv->stage, 0, sv->g.R, 0, 0, sv->g.R, sv->st);
+    if (rc) return rc;
+  } else
   LBM_CHECK_HIP(hipMemcpy2DAsync(sv->lat[sv->cur], (size_t)sv->g.plane_stride * sizeof(double),
                                  host.data(), plane_bytes, plane_bytes, 9, hipMemcpyHostToDevice, sv->st));
   LBM_CHECK_HIP(hipStreamSynchronize(sv->st));

@@ -81,9 +81,9 @@ __device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restr
   if (INTERIOR) {
     const long o = g.at(gr, gc);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) fr[q] = in_r[q * g.plane + (o - icx(q) * g.C - icy(q))];
+    for (int q = 0; q < Q; ++q) fr[q] = in_r[q * g.plane + (o - icx(q) * g.P - icy(q))];
 #pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] = in_b[q * g.plane + (o - icx(q) * g.C - icy(q))];
+    for (int q = 0; q < Q; ++q) ft[q] = in_b[q * g.plane + (o - icx(q) * g.P - icy(q))];
   } else {
     gather_bc(fr, in_r, g, bc, gr, gc);
     gather_bc(ft, in_b, g, bc, gr, gc);
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(TR* WC * 64, PF ? 3 : 4) void k_cg_walk(
   unsigned goff[Q], poff[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    goff[q] = (unsigned)((q * g.plane - icx(q) * g.C - icy(q)) * 8);
+    goff[q] = (unsigned)((q * g.plane - icx(q) * g.P - icy(q)) * 8);
     poff[q] = (unsigned)(q * g.plane * 8);
   }
   double raw_r[Q], raw_b[Q];
@@ -653,7 +653,7 @@ __global__ __launch_bounds__(TR* WC * 64, PF ? 3 : 4) void k_cg_walk(
     asm volatile("" : "+v"(l));
     const int c = c_base - 2 + l;
     const int dl = (c > g.C - 2 ? g.C - 2 : c) - (c_base - 3);  // loads stay inside the lattice (such lanes feed nothing stored)
-    const unsigned v = (unsigned)((rn - (R0 - 3)) * g.C + dl) * 8u;
+    const unsigned v = (unsigned)((rn - (R0 - 3)) * g.P + dl) * 8u;
 #pragma unroll
     for (int q = 0; q < Q; ++q) raw_r[q] = cg_ld(in_r + o, goff[q] + v);
 #pragma unroll
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(TR* WC * 64, PF ? 3 : 4) void k_cg_walk(
   bool stored = true;
   auto flush = [&](int Rp, int l) {
     const int m = parks ? tr - (TR - 2) : tr + 2;
-    const unsigned v_out = (unsigned)(m * g.C + l) * 8u;  // from (Rp, c_base - 2)
+    const unsigned v_out = (unsigned)(m * g.P + l) * 8u;  // from (Rp, c_base - 2)
     const long o_out = g.at(Rp, c_base - 2);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -674,12 +674,13 @@ __global__ __launch_bounds__(TR* WC * 64, PF ? 3 : 4) void k_cg_walk(
     }
     if (WITH_FIELDS) {
       const long o = mi.at(Rp, c_base - 2), oo = (long)Rp * g.C + (c_base - 2);  // diagnostics carry no ghost rows
-      cg_st(of[0], rho_r_out + o, v_out);
-      cg_st(of[1], rho_b_out + o, v_out);
-      cg_st(of[2], u_out + o, v_out);
-      cg_st(of[3], u_out + (mi.n + o), v_out);
-      cg_st(of[4], psi_out + oo, v_out);
-      cg_st(of[5], snu_out + oo, v_out);
+      const unsigned v_f = (unsigned)(m * g.C + l) * 8u;  // the fields are dense: rows C apart, whatever the lattice's pitch
+      cg_st(of[0], rho_r_out + o, v_f);
+      cg_st(of[1], rho_b_out + o, v_f);
+      cg_st(of[2], u_out + o, v_f);
+      cg_st(of[3], u_out + (mi.n + o), v_f);
+      cg_st(of[4], psi_out + oo, v_f);
+      cg_st(of[5], snu_out + oo, v_f);
     }
   };
   if (PF) issue(-KW);

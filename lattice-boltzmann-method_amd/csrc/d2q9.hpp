@@ -37,12 +37,14 @@ __host__ __device__ __forceinline__ constexpr int opp(int q) {
 // Geometry of one SoA lattice (device copy of lbm_geom + derived strides).
 struct Geom {
   int R, C, ghost;
-  long plane;  // doubles per population plane = (R + 2*ghost) * C
-  __host__ __device__ long at(int r, int c) const { return (long)(r + ghost) * C + c; }
+  long plane;  // doubles per population plane >= (R + 2*ghost) * P
+  int P;       // doubles per row of a plane (row pitch) >= C: lbm_geom.row_pitch; C itself stays the WIDTH of the lattice
+  __host__ __device__ long at(int r, int c) const { return (long)(r + ghost) * P + c; }
 };
 inline Geom make_geom(const lbm_geom& g) {
-  const long dense = (long)(g.R + 2 * g.ghost) * g.C;
-  return Geom{g.R, g.C, g.ghost, g.plane_stride > 0 ? (long)g.plane_stride : dense};
+  const int P = g.row_pitch > 0 ? g.row_pitch : g.C;
+  const long dense = (long)(g.R + 2 * g.ghost) * P;
+  return Geom{g.R, g.C, g.ghost, g.plane_stride > 0 ? (long)g.plane_stride : dense, P};
 }
 
 struct Bc {

@@ -14,7 +14,9 @@ inline int validate_geom_bc(const char* fn, const lbm_geom* g, const lbm_bc* bc,
   LBM_REQUIRE(g, "%s: NULL geometry", fn);
   LBM_REQUIRE(g->R >= 1 && g->C >= 1, "%s: R=%d C=%d must be positive", fn, g->R, g->C);
   LBM_REQUIRE(g->ghost >= 0 && g->ghost <= 15, "%s: ghost=%d must be 0..15", fn, g->ghost);
-  LBM_REQUIRE(g->plane_stride == 0 || g->plane_stride >= (long long)(g->R + 2 * g->ghost) * g->C,
+  LBM_REQUIRE(g->row_pitch == 0 || (g->row_pitch >= g->C && g->row_pitch % 2 == 0), "%s: row_pitch=%d must be even and >= C=%d (0 = dense)",
+              fn, g->row_pitch, g->C);
+  LBM_REQUIRE(g->plane_stride == 0 || g->plane_stride >= (long long)(g->R + 2 * g->ghost) * (g->row_pitch > 0 ? g->row_pitch : g->C),
               "%s: plane_stride=%lld smaller than a plane", fn, g->plane_stride);
   if (bc) {
     auto row_ok = [](int m) {

@@ -405,6 +405,91 @@ def test_cg_step_in_two_parts_equals_one_call(lib, oracle, R, C, edge):
             assert torch.equal(got[k][:, ghost:ghost + R], want[k][:, ghost:ghost + R]), (ghost, k)
 
 
+@pytest.mark.parametrize("R,C,pad", [(96, 200, 8), (130, 1040, 64), (64, 32, 2)])
+def test_cg_steps_on_row_padded_lattices_equal_dense_ones(lib, oracle, R, C, pad):
+    """lbm_geom.row_pitch (round 4): the same two-phase steps on lattices whose rows are `pad` doubles apart from dense --
+    one-launch step (inner tile kernel + frame), the two-part form and the reference-order two-pass step -- leave the same
+    bits in the nodes; the padding columns are never touched"""
+    import ctypes as ct
+    from gpu_util import dev, upload_soa
+    from pylbm import _ptr
+    po = pyoracle.cg_params(R, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    bc = pylbm.Bc()
+    lib.raw.lbm_cg_default_bc(ct.byref(bc))
+    flat = pylbm.Geom(R, C, 0)
+    P = C + pad
+    wide = pylbm.Geom(R, C, 0, R * P, P)
+    f_r, f_b = upload_soa(lib, s0["f_r"]), upload_soa(lib, s0["f_b"])
+    rr, rb, uu = upload_soa(lib, s0["rho_r"]), upload_soa(lib, s0["rho_b"]), upload_soa(lib, s0["u"])
+    p0 = [torch.empty((9, R, C), dtype=torch.float64, device=dev()) for _ in range(2)]
+    lib.cg_collide(_ptr(p0[0]), _ptr(p0[1]), _ptr(f_r), _ptr(f_b), _ptr(rr), _ptr(rb), _ptr(uu),
+                   ct.byref(flat), ct.byref(bc), ct.byref(pg), None, None, None)
+
+    def padded(t):
+        w = torch.full((9, R, P), 777.0, dtype=torch.float64, device=dev())
+        w[:, :, :C] = t
+        return w
+
+    # the first collision on padded lattices, too
+    q0 = [torch.full((9, R, P), 777.0, dtype=torch.float64, device=dev()) for _ in range(2)]
+    fw = [padded(f_r), padded(f_b)]     # (kept alive: _ptr() of a temporary would dangle)
+    lib.cg_collide(_ptr(q0[0]), _ptr(q0[1]), _ptr(fw[0]), _ptr(fw[1]), _ptr(rr), _ptr(rb), _ptr(uu),
+                   ct.byref(wide), ct.byref(bc), ct.byref(pg), None, None, None)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(q0[k][:, :, :C], p0[k]) and bool((q0[k][:, :, C:] == 777.0).all())
+    for form in ("fused", "parts", "two_pass"):
+        a = [x.clone() for x in p0]
+        b = [torch.empty_like(x) for x in p0]
+        aw = [padded(x) for x in p0]
+        bw = [torch.full((9, R, P), 777.0, dtype=torch.float64, device=dev()) for _ in range(2)]
+        for _ in range(4):
+            for (src, dst, g) in ((a, b, flat), (aw, bw, wide)):
+                if form == "fused":
+                    lib.cg_step_fused(_ptr(dst[0]), _ptr(dst[1]), _ptr(src[0]), _ptr(src[1]), ct.byref(g), ct.byref(bc), ct.byref(pg), 0, R,
+                                      None, None, None, None, None, None)
+                elif form == "parts":
+                    for part in (pylbm.CG_PART_FRAME, pylbm.CG_PART_INNER):
+                        lib.cg_step_fused_part(_ptr(dst[0]), _ptr(dst[1]), _ptr(src[0]), _ptr(src[1]), ct.byref(g), ct.byref(bc), ct.byref(pg),
+                                               part, 16, None, None, None, None, None, None)
+                else:
+                    t_rr, t_rb, t_u = torch.empty_like(rr), torch.empty_like(rb), torch.empty_like(uu)
+                    lib.cg_stream_moments(_ptr(t_rr), _ptr(t_rb), _ptr(t_u), _ptr(src[0]), _ptr(src[1]), ct.byref(g), ct.byref(bc), ct.byref(pg), None)
+                    lib.cg_stream_collide(_ptr(dst[0]), _ptr(dst[1]), _ptr(src[0]), _ptr(src[1]), _ptr(t_rr), _ptr(t_rb), _ptr(t_u),
+                                          ct.byref(g), ct.byref(bc), ct.byref(pg), 0, R, None, None, None)
+            a, b = b, a
+            aw, bw = bw, aw
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(aw[k][:, :, :C], a[k]), (form, k)
+            assert bool((aw[k][:, :, C:] == 777.0).all()), (form, k, "padding columns written")
+
+
+def test_cg_solver_pads_its_rows_and_leaves_the_same_state(lib, oracle):
+    """lbm_cg_solver_create pads its lattices' rows where C * 8 bytes is a multiple of 4 KiB (lbm_default_row_pitch; tuning
+    "row_pad" = 0: dense): same state bit for bit through set_state / step / get_state, fields and populations"""
+    R, C, n = 48, 1024, 6
+    assert lib.raw.lbm_default_row_pitch(C) == C + 64 and lib.raw.lbm_default_row_pitch(1000) == 1000
+    po = pyoracle.cg_params(R, C)
+    pg = pylbm.cg_params()
+    s0 = oracle.cg_init(po)
+    got = {}
+    try:
+        for pad in (0, -1):
+            lib.set_tuning(b"row_pad", pad)
+            sv = pylbm.CgSolver(lib, R, C, pg)
+            sv.set_state(s0["f_r"], s0["f_b"], s0["rho_r"], s0["rho_b"], s0["u"])
+            sv.step(n)
+            got[pad] = sv.get_state()
+            sv.close()
+    finally:
+        lib.set_tuning(b"row_pad", -1)
+    for k in got[0]:
+        assert bits_equal(got[-1][k], got[0][k]), k
+
+
 # ---- row a13: class differential (src/differential.hpp:48-51, src/differential.cpp:23-39) --------
 def _diff5_gpu(lib, psi, d):
     R, C = psi.shape

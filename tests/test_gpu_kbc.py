@@ -351,3 +351,45 @@ def test_two_solvers_with_different_collision_forms_coexist(lib, oracle):
     assert bits_equal(together[0], f_o), ulp_diff(together[0], f_o)
     for key in (b"bgk_fast", b"kbc_fast"):
         assert lib.raw.lbm_get_tuning(key) == 0      # unset (lbm_get_tuning reports 0 for keys nobody set)
+
+
+@pytest.mark.parametrize("case", ["periodic", "pressure_rows"])
+def test_kbc_solver_pads_its_rows_and_leaves_the_same_state(lib, oracle, tmp_path, case):
+    """lbm_solver_create pads the rows of a KBC solver's lattices where C * 8 bytes is a multiple of 4 KiB
+    (lbm_default_row_pitch, round 4; tuning "row_pad" = 0: dense rows): the same populations and moments bit for bit --
+    multi-step windows + single steps, the held-moments start and the pressure-row blocks with their seam copies,
+    get / set on the device, checkpoint save on a padded solver -> load on a dense one"""
+    R, C = 96, 1024
+    assert lib.raw.lbm_default_row_pitch(C) == C + 64
+    if case == "periodic":
+        m0, m1 = oracle.kbc_shear_init(R, C)
+        f0 = oracle.kbc_equilibrium(m0, m1)
+        s2, bc, n = 1.0 / (0.5 + 3 * 1.7e-4), None, 11
+    else:
+        s2, rin, bc = _upo_case(R, C)
+        f0, n = np.zeros((R, C, 9)), 1 + 2 * 4 + 1
+    got = {}
+    try:
+        for pad in (0, -1):
+            lib.set_tuning(b"row_pad", pad)
+            sv = pylbm.Solver(lib, pylbm.MODEL_KBC, R, C, pylbm.KbcParams(s2), bc=bc)
+            sv.set_f(f0)
+            if case == "pressure_rows":
+                sv.set_moments(np.ones((R, C)), np.zeros((R, C, 2)))
+            sv.step(n, record_moments=True)
+            rho, u = sv.moments()
+            if pad == -1:
+                sv.checkpoint_save(tmp_path / "ck.bin")
+            got[pad] = (sv.get_f(), rho, u)
+            sv.close()
+        # the padded solver's checkpoint restarts a dense one
+        lib.set_tuning(b"row_pad", 0)
+        sv = pylbm.Solver(lib, pylbm.MODEL_KBC, R, C, pylbm.KbcParams(s2), bc=bc)
+        sv.checkpoint_load(tmp_path / "ck.bin")
+        f_ck = sv.get_f()
+        sv.close()
+    finally:
+        lib.set_tuning(b"row_pad", -1)
+    for a, b in zip(got[-1], got[0]):
+        assert bits_equal(a, b), ulp_diff(a, b)
+    assert bits_equal(f_ck, got[0][0])
