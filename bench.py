@@ -165,8 +165,36 @@ def _strip_args(argv, names_with_value=(), flags=()):
     return out
 
 
+def _die_with_parent():
+    """in the worker, between fork and exec: SIGKILL when the supervisor dies (PR_SET_PDEATHSIG), so that no worker
+    outlives a supervisor the launcher has killed and keeps its GPU"""
+    try:
+        ct.CDLL("libc.so.6", use_errno=True).prctl(1, 9)
+    except OSError:
+        pass
+
+
 def supervise(a, argv):
     """Returns the exit code.  Never initialises the GPU (torch.cuda.device_count() does not)."""
+    import signal
+    current = {"proc": None}
+
+    def _on_signal(signum, _frame):                     # the launcher (or the driver's time limit) ends this rank: take the worker along
+        p_ = current["proc"]
+        if p_ is not None and p_.poll() is None:
+            p_.kill()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, _on_signal)
+    try:
+        return _supervise(a, argv, current)
+    finally:
+        p_ = current["proc"]
+        if p_ is not None and p_.poll() is None:        # an exception on the way (a peer supervisor gone, a collective that timed out)
+            _end_process(p_, grace=2.0)
+
+
+def _supervise(a, argv, current):
     import datetime
     import torch
     import torch.distributed as dist
@@ -211,7 +239,8 @@ def supervise(a, argv):
         with open(stem + ".out", "w") as fo, open(stem + ".err", "w") as fe:
             proc = subprocess.Popen([sys.executable, script] + worker_argv +
                                     ["--worker", "--status-file", stem + ".stage", "--transport", transport, "--ctl", ctlb,
-                                     "--attempt", str(attempt)], env=env, stdout=fo, stderr=fe)
+                                     "--attempt", str(attempt)], env=env, stdout=fo, stderr=fe, preexec_fn=_die_with_parent)
+        current["proc"] = proc                          # (the signal handler and the exception path end exactly this child)
         t0, verdict, table = time.time(), None, None
         while verdict is None:
             time.sleep(0.2)

@@ -23,6 +23,9 @@ def stage(w):
 
 
 stage("start")
+if os.environ.get("LBM_FAKE_PID_DIR"):      # (the tests check that no worker outlives its supervisor)
+    with open(os.path.join(os.environ["LBM_FAKE_PID_DIR"], f"worker{rank}.pid"), "w") as fh:
+        fh.write(str(os.getpid()))
 stall = os.environ.get("LBM_BENCH_STALL", "")
 if stall in (f"{rank}:{a.attempt}", f"{rank}:*"):
     time.sleep(3600)

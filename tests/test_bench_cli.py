@@ -93,6 +93,39 @@ def test_an_unsupervised_happy_path_reports_one_attempt():
     assert d["launcher"]["attempts"] == 1 and "transport_fallback" not in d["launcher"]
 
 
+def test_no_worker_outlives_a_supervisor_that_is_killed(tmp_path):
+    """the launcher (or the driver's time limit) ends the rank processes: every worker goes with its supervisor -- SIGTERM is
+    handled (the worker is killed first), and a SIGKILLed supervisor's worker gets PR_SET_PDEATHSIG"""
+    import signal
+    import socket
+    import time
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    fake = os.path.join(ROOT, "tests", "fake_bench_worker.py")
+    procs = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                 LBM_BENCH_STALL=f"{r}:*", LBM_FAKE_PID_DIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--share-gpu", "--worker-script", fake, "--ring-deadline", "300"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e))
+    t0 = time.time()
+    while time.time() - t0 < 60 and not all((tmp_path / f"worker{r}.pid").exists() for r in range(2)):
+        time.sleep(0.1)
+    pids = [int((tmp_path / f"worker{r}.pid").read_text()) for r in range(2)]
+    procs[0].send_signal(signal.SIGTERM)
+    procs[1].send_signal(signal.SIGKILL)
+    for p in procs:
+        p.wait(timeout=30)
+    time.sleep(1.0)
+    for pid in pids:   # gone, or a zombie waiting for init to reap it
+        try:
+            state = open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0]
+        except OSError:
+            state = "gone"
+        assert state in ("gone", "Z", "X"), (pid, state)
+
+
 @pytest.mark.gpu
 def test_real_workers_restart_after_a_stalled_ring_on_one_gpu():
     """the same on the GPU with real workers: rank 1's first worker stalls before creating its ring; the second set of
