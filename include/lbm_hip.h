@@ -114,6 +114,11 @@ typedef struct lbm_geom {
                              Must be even and >= C.  Entry points that take a lattice honour it; buffers of
                              macroscopic fields (rho, u, psi ...) and AoS arrays are always dense. */
 } lbm_geom;
+/* rows [src_row, src_row + n_rows) of all 9 planes of `src` (geometry sg) into rows [dst_row, ...) of `dst` (geometry dg):
+ * a node-addressed copy (row indices in owned-row numbering, ghost rows allowed), so that padded rows / planes and ghost
+ * rows on either side do not matter; sg->C == dg->C.  For hosts that hold lattices of their own in a padded layout. */
+int lbm_lattice_copy_rows(double* dst, const lbm_geom* dg, int dst_row, const double* src, const lbm_geom* sg,
+                          int src_row, int n_rows, lbm_stream_t s);
 /* the row pitch the solver contexts use for a lattice of C columns: C + 64 doubles where C * 8 bytes is a multiple
  * of 4 KiB and C >= 1024 (tuning "row_pad": that many doubles instead of 64, 0 = never), else C */
 int lbm_default_row_pitch(int C);

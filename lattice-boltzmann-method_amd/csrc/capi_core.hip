@@ -525,6 +525,14 @@ int lbm_soa_to_aos_ex(double* aos, const double* soa, int R, int C, int Qn,
                       long long plane_stride, lbm_stream_t s) {
   return lbm_soa_to_aos_pitched(aos, soa, R, C, Qn, plane_stride, 0, s);
 }
+int lbm_lattice_copy_rows(double* dst, const lbm_geom* dg, int dst_row, const double* src, const lbm_geom* sg,
+                          int src_row, int n_rows, lbm_stream_t s) {
+  LBM_REQUIRE(dst && src && dg && sg && dg->C == sg->C && n_rows >= 0, "lbm_lattice_copy_rows: bad argument");
+  int rc = validate_geom_bc("lbm_lattice_copy_rows", dg, nullptr, false);
+  if (!rc) rc = validate_geom_bc("lbm_lattice_copy_rows", sg, nullptr, false);
+  if (rc) return rc;
+  return box_copy(dst, *dg, dst_row, 0, src, *sg, src_row, 0, n_rows, dg->C, as_stream(s));
+}
 int lbm_default_row_pitch(int C) {
   // rows a power of two apart (C * 8 bytes a multiple of 4 KiB) land on the same L2 sets and DRAM pages: the two-phase tile
   // kernel gains 4 % at 2112 or 1984 columns over 2048, the KBC window 3 % (profiles/r04_row_stride_probe.txt); the BGK

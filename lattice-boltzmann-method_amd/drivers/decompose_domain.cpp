@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
       Block(int H, int W) : adve(H, W, 9), coll(H, W, 9), equi(H, W, 9), u(H, W, 2), rho(H, W, 1) {}
     };
     Block A(H, W), B(H, W);
-    const lbm_geom g{H, W, 0, 0};
+    const lbm_geom g{H, W, 0, 0, 0};
     for (Block* b : {&A, &B}) {  // m_0 = 1, m_1 = 0, adve_f = equilibrium (:105-123)
       b->rho.fill(1.0);
       b->u.fill(0.0);

@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 4; ++k) {
       b[k].R = shape[k][0];
       b[k].C = shape[k][1];
-      b[k].g = geoms[k] = lbm_geom{b[k].R, b[k].C, 0, 0};
+      b[k].g = geoms[k] = lbm_geom{b[k].R, b[k].C, 0, 0, 0};
       const size_t n = (size_t)b[k].R * b[k].C;
       for (double** p : {&b[k].adve, &b[k].coll}) lbm::check(lbm_malloc((void**)p, n * 9 * sizeof(double)));
       lbm::check(lbm_malloc((void**)&b[k].rho, n * sizeof(double)));

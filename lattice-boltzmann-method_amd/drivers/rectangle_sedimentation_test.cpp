@@ -107,7 +107,7 @@ int main(int argc, char* argv[]) {
       }
       lbm::check(lbm_memcpy_h2d(terms, a.data(), a.size() * sizeof(double), nullptr));
     }
-    const lbm_geom geom{X, Y, 0, 0};
+    const lbm_geom geom{X, Y, 0, 0, 0};
     // f: post-advect assignments in the driver's order (:148-194)
     lbm_links* lf = nullptr;
     lbm::check(lbm_links_create(&lf, 1, &geom));

@@ -91,7 +91,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   const int R = a.rows, C = a.cols, D = a.depth, Rg = R * world;
   // ghost = period x D rows: lbm_ring_bgk_step / _kbc_step exchange once per `period` launches
   const int G = D * (D < 2 ? 1 : a.period);
-  lbm_geom g{R, C, G, 0};
+  lbm_geom g{R, C, G, 0, 0};
   lbm_bgk_params prm{};
   prm.omega = a.omega;
   lbm_kbc_params kprm{a.omega, LBM_FORM_DEFAULT};
@@ -158,7 +158,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
     write_file_atomic(a.id_file + ".f" + std::to_string(rank), own.data(), own.size() * sizeof(double));
     if (rank == 0) {
       Args whole = a;
-      lbm_geom gw{Rg, C, 0, 0};
+      lbm_geom gw{Rg, C, 0, 0, 0};
       double* p = make_slab(whole, Rg, 0, Rg, gw, prm);
       double* q2 = nullptr;
       const size_t n = (size_t)9 * Rg * C;

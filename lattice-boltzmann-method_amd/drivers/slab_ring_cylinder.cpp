@@ -146,7 +146,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   for (int r = 1; r < vw; ++r) row0s[r] = row0s[r - 1] + heights[r - 1];
   if (row0s[vw - 1] + heights[vw - 1] != Rg) throw std::runtime_error("slab heights do not add up to the domain");
   const int R = heights[vr];
-  lbm_geom g{R, C, G, 0};
+  lbm_geom g{R, C, G, 0, 0};
   lbm_slab_ibm* sl = nullptr;
   check(lbm_slab_ibm_create(&sl, &g, row0s[vr], Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB),
         "lbm_slab_ibm_create");
@@ -201,7 +201,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
     write_file_atomic(a.id_file + ".f" + std::to_string(rank), own.data(), own.size() * 8);
     if (rank == 0) {
       // the same run as ONE block through the solver context (collide-first, forced blocks)
-      lbm_geom gw{Rg, C, 0, 0};
+      lbm_geom gw{Rg, C, 0, 0, 0};
       lbm_solver* sv = nullptr;
       check(lbm_solver_create(&sv, LBM_MODEL_BGK, &gw, &bc, &prm, nullptr), "lbm_solver_create");
       lbm_ibm* ibw = nullptr;
@@ -296,7 +296,7 @@ int run_emulated(const Args& a, int N) {
     S[r].row0 = row0[r];
     S[r].n = (size_t)rows[r] * C;
     S[r].plane = (size_t)(rows[r] + 2 * G) * C;
-    S[r].g = lbm_geom{rows[r], C, G, 0};
+    S[r].g = lbm_geom{rows[r], C, G, 0, 0};
     check(lbm_slab_ibm_create(&S[r].sl, &S[r].g, S[r].row0, Rg, &bc, &prm, D, mx.data(), my.data(), (int)mx.size(), 5, kGuoA, kGuoB), "lbm_slab_ibm_create");
     check(lbm_slab_ibm_info(S[r].sl, &S[r].owner, &S[r].sp, &S[r].sn, &b0, &b1), "lbm_slab_ibm_info");
     for (int k = 0; k < 2; ++k) {
@@ -374,7 +374,7 @@ int run_emulated(const Args& a, int N) {
       else if (std::memcmp(F, Fs, sizeof F) != 0) ++bad;  // co-owners hold the same forcing
     }
   if (a.check) {
-    lbm_geom gw{Rg, C, 0, 0};
+    lbm_geom gw{Rg, C, 0, 0, 0};
     lbm_solver* sv = nullptr;
     check(lbm_solver_create(&sv, LBM_MODEL_BGK, &gw, &bc, &prm, nullptr), "lbm_solver_create");
     lbm_ibm* ibw = nullptr;

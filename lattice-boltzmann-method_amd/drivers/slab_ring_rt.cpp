@@ -41,13 +41,28 @@ lbm_cg_params rt_params() {
   return p;
 }
 
+// geometry of a slab's lattices: rows padded off a power-of-two stride like the solver contexts' (lbm_default_row_pitch:
+// +3 % for the two-phase kernel at 2048 columns); `dense` = as the reference holds its tensors
+lbm_geom slab_geom(int R, int C, int G, bool dense = false) {
+  const int pitch = dense ? C : lbm_default_row_pitch(C);
+  return lbm_geom{R, C, G, (long long)(R + 2 * G) * pitch, pitch > C ? pitch : 0};
+}
+size_t plane_of(const lbm_geom& g) { return (size_t)g.plane_stride; }
+// the owned rows of a lattice as 9 dense planes [9][R][C] on the host
+void owned_rows_to_host(double* host, const double* lattice, const lbm_geom& g, double* dense_dev) {
+  const lbm_geom d{g.R, g.C, 0, 0, 0};
+  check(lbm_lattice_copy_rows(dense_dev, &d, 0, lattice, &g, 0, g.R, nullptr), "lbm_lattice_copy_rows");
+  check(lbm_memcpy_d2h(host, dense_dev, (size_t)9 * g.R * g.C * 8, nullptr), "d2h");
+  check(lbm_stream_sync(nullptr), "sync");
+}
+
 // Post-collision lattices of rows [row0, row0 + R) of an Rg x C domain, ghost rows G (0 or 3):
 // densities by init_rho_cosine, f = feq(rho_k, u = 0), then the driver's first collision
 // (lbm_cg_collide on the given rho, u).  The macroscopic arrays of a slab carry 2 ghost rows.
 void make_slab(int R, int C, int row0, int Rg, const lbm_geom& g, const lbm_bc& bc,
                const lbm_cg_params& prm, double** post_r, double** post_b) {
   const int G = g.ghost, mg = G ? 2 : 0;
-  const size_t plane = (size_t)(R + 2 * G) * C, mplane = (size_t)(R + 2 * mg) * C;
+  const size_t plane = plane_of(g), mplane = (size_t)(R + 2 * mg) * C;
   std::vector<double> hr(mplane), hb(mplane);
   for (int r = -mg; r < R + mg; ++r) {
     int gr = row0 + r;
@@ -71,9 +86,18 @@ void make_slab(int R, int C, int row0, int Rg, const lbm_geom& g, const lbm_bc& 
   check(lbm_memcpy_h2d(d_rb, hb.data(), mplane * 8, nullptr), "h2d");
   check(lbm_memset(d_u, 0, 2 * mplane * 8, nullptr), "memset");
   for (double* p : {pre_r, pre_b, *post_r, *post_b}) check(lbm_memset(p, 0, 9 * plane * 8, nullptr), "memset");
-  // feq on the owned rows, written straight into the ghosted lattices (u = 0: dense zeros)
-  check(lbm_cg_equilibrium(pre_r + (size_t)G * C, d_rr + (size_t)mg * C, d_u, &prm.red, R, C, (long long)plane, nullptr), "lbm_cg_equilibrium");
-  check(lbm_cg_equilibrium(pre_b + (size_t)G * C, d_rb + (size_t)mg * C, d_u, &prm.blue, R, C, (long long)plane, nullptr), "lbm_cg_equilibrium");
+  // feq on the owned rows (u = 0: dense zeros) as dense planes, then into the ghosted, row-padded lattices
+  {
+    double* eq = nullptr;
+    check(lbm_malloc((void**)&eq, (size_t)9 * R * C * 8), "lbm_malloc");
+    const lbm_geom dense{R, C, 0, 0, 0};
+    check(lbm_cg_equilibrium(eq, d_rr + (size_t)mg * C, d_u, &prm.red, R, C, 0, nullptr), "lbm_cg_equilibrium");
+    check(lbm_lattice_copy_rows(pre_r, &g, 0, eq, &dense, 0, R, nullptr), "lbm_lattice_copy_rows");
+    check(lbm_cg_equilibrium(eq, d_rb + (size_t)mg * C, d_u, &prm.blue, R, C, 0, nullptr), "lbm_cg_equilibrium");
+    check(lbm_lattice_copy_rows(pre_b, &g, 0, eq, &dense, 0, R, nullptr), "lbm_lattice_copy_rows");
+    check(lbm_stream_sync(nullptr), "sync");
+    lbm_free(eq);
+  }
   check(lbm_cg_collide(*post_r, *post_b, pre_r, pre_b, d_rr, d_rb, d_u, &g, &bc, &prm, nullptr, nullptr, nullptr), "lbm_cg_collide");
   check(lbm_stream_sync(nullptr), "sync");
   for (double* p : {d_rr, d_rb, d_u, pre_r, pre_b}) lbm_free(p);
@@ -83,7 +107,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   check(lbm_set_device(a.one_gpu ? 0 : local_rank), "lbm_set_device");
   const int R = a.rows, C = a.cols, Rg = R * world, G = 3;
   const lbm_cg_params prm = rt_params();
-  lbm_geom g{R, C, G, 0};
+  const lbm_geom g = slab_geom(R, C, G);
   lbm_bc bc;
   lbm_cg_default_bc(&bc);
   if (rank > 0) bc.row_lo = LBM_EDGE_HALO;
@@ -94,7 +118,7 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
   lbm_ring* ring = nullptr;
   check(lbm_ring_create(&ring, id, rank, world, &g, /*periodic=*/0), "lbm_ring_create");
 
-  const size_t plane = (size_t)(R + 2 * G) * C;
+  const size_t plane = plane_of(g);
   double* lat[2][2];
   make_slab(R, C, rank * R, Rg, g, bc, prm, &lat[0][0], &lat[0][1]);
   for (int k = 0; k < 2; ++k) {
@@ -121,16 +145,14 @@ int run_rank(const Args& a, int rank, int world, int local_rank) {
 
   int bad = 0;
   if (a.check) {
-    std::vector<double> h(9 * plane), own((size_t)18 * R * C);
-    for (int k = 0; k < 2; ++k) {
-      check(lbm_memcpy_d2h(h.data(), lat[cur][k], h.size() * 8, nullptr), "d2h");
-      check(lbm_stream_sync(nullptr), "sync");
-      for (int q = 0; q < 9; ++q)
-        std::memcpy(&own[((size_t)k * 9 + q) * R * C], &h[q * plane + (size_t)G * C], (size_t)R * C * 8);
-    }
+    std::vector<double> own((size_t)18 * R * C);
+    double* dense_dev = nullptr;
+    check(lbm_malloc((void**)&dense_dev, (size_t)9 * R * C * 8), "lbm_malloc");
+    for (int k = 0; k < 2; ++k) owned_rows_to_host(&own[(size_t)k * 9 * R * C], lat[cur][k], g, dense_dev);
+    lbm_free(dense_dev);
     write_file_atomic(a.id_file + ".f" + std::to_string(rank), own.data(), own.size() * 8);
     if (rank == 0) {
-      lbm_geom gw{Rg, C, 0, 0};
+      const lbm_geom gw = slab_geom(Rg, C, 0, /*dense=*/true);
       lbm_bc bw;
       lbm_cg_default_bc(&bw);
       double *p[2], *q2[2];
@@ -182,8 +204,8 @@ int run_emulated(const Args& a, int N) {
   const int R = a.rows, C = a.cols, Rg = R * N, G = 3, E = a.edge_rows < G ? G : a.edge_rows;
   if (2 * E >= R) throw std::runtime_error("--edge-rows too large for these slabs");
   const lbm_cg_params prm = rt_params();
-  const lbm_geom g{R, C, G, 0};
-  const size_t plane = (size_t)(R + 2 * G) * C, msg = (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * C;
+  const lbm_geom g = slab_geom(R, C, G);
+  const size_t plane = plane_of(g), msg = (size_t)lbm_halo_rows(LBM_HALO_TWO_PHASE) * C;
   struct Slab {
     lbm_bc bc;
     double* lat[2][2];   // [buffer][colour]
@@ -281,7 +303,7 @@ int run_emulated(const Args& a, int N) {
   lbm_stream_destroy(edge);
   int bad = 0;
   if (a.check) {
-    lbm_geom gw{Rg, C, 0, 0};
+    const lbm_geom gw = slab_geom(Rg, C, 0, /*dense=*/true);
     lbm_bc bw;
     lbm_cg_default_bc(&bw);
     double *p[2], *q2[2];
@@ -293,15 +315,19 @@ int run_emulated(const Args& a, int N) {
       std::swap(p[0], q2[0]);
       std::swap(p[1], q2[1]);
     }
-    std::vector<double> want((size_t)R * C), got((size_t)R * C);
+    std::vector<double> want((size_t)R * C), got((size_t)9 * R * C);
+    double* dense_dev = nullptr;
+    check(lbm_malloc((void**)&dense_dev, (size_t)9 * R * C * 8), "lbm_malloc");
     for (int k = 0; k < 2; ++k)
-      for (int q = 0; q < 9; ++q)
-        for (int r = 0; r < N; ++r) {
+      for (int r = 0; r < N; ++r) {
+        owned_rows_to_host(got.data(), S[r].lat[cur][k], g, dense_dev);
+        for (int q = 0; q < 9; ++q) {
           check(lbm_memcpy_d2h(want.data(), p[k] + (size_t)q * Rg * C + (size_t)r * R * C, want.size() * 8, nullptr), "d2h");
-          check(lbm_memcpy_d2h(got.data(), S[r].lat[cur][k] + q * plane + (size_t)G * C, got.size() * 8, nullptr), "d2h");
           check(lbm_stream_sync(nullptr), "sync");
-          if (std::memcmp(want.data(), got.data(), want.size() * 8) != 0) ++bad;
+          if (std::memcmp(want.data(), &got[(size_t)q * R * C], want.size() * 8) != 0) ++bad;
         }
+      }
+    lbm_free(dense_dev);
     for (int k = 0; k < 2; ++k) {
       lbm_free(p[k]);
       lbm_free(q2[k]);

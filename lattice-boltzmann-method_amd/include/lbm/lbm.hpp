@@ -151,7 +151,7 @@ class Solver {  // single-phase BGK / KBC block, wraps lbm_solver
 
  private:
   Solver(int model, int R, int C, const void* prm, const lbm_bc& bc) : R_(R), C_(C) {
-    lbm_geom g{R, C, 0, 0};
+    lbm_geom g{R, C, 0, 0, 0};
     check(lbm_solver_create(&h_, model, &g, &bc, prm, nullptr));
   }
   lbm_solver* h_ = nullptr;
@@ -318,7 +318,7 @@ class CgSolver {
   CgSolver(int R, int C, const colour& red, const colour& blue, double sigma, double gravity_r,
            double delta = 0.1, double gravity_c = 0.0, bool add_source = true)
       : R_(R), C_(C) {
-    lbm_geom g{R, C, 0, 0};
+    lbm_geom g{R, C, 0, 0, 0};
     lbm_cg_params p{red.abi(), blue.abi(), sigma, gravity_r, gravity_c, add_source ? 1 : 0, delta, LBM_FORM_DEFAULT};
     check(lbm_cg_solver_create(&h_, &g, nullptr, &p, nullptr));
   }

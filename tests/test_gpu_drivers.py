@@ -188,6 +188,23 @@ def test_slab_ring_rt_emulated_chain_of_four_slabs(tmp_path):
     assert line["check"] == "bitwise equal to one block" and line["slabs"] == 4 and line["message_rows_per_colour_and_side"] == 21
 
 
+def test_slab_ring_rt_with_row_padded_slabs(tmp_path):
+    """1024 columns: slab_geom pads the rows of the slabs' lattices (lbm_default_row_pitch) -- init through
+    lbm_lattice_copy_rows, ring pack / unpack, the two-part step and the check all on padded lattices; the emulated chain
+    and two real rank processes, both bitwise against the dense single block"""
+    import json
+    exe = os.path.join(BIN, "slab_ring_rt")
+    r = subprocess.run([exe, "--emulate", "3", "--rows", "48", "--cols", "1024", "--steps", "7", "--warmup", "2", "--edge-rows", "16",
+                        "--check", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["check"] == "bitwise equal to one block"
+    r = subprocess.run([exe, "--spawn", "2", "--transport", "ipc", "--one-gpu", "1", "--check", "1", "--id-file", str(tmp_path / "id"),
+                        "--rows", "48", "--cols", "1024", "--steps", "6", "--warmup", "2", "--edge-rows", "16"],
+                       capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["check"] == "bitwise equal to one block"
+
+
 @pytest.mark.parametrize("driver,args", [
     ("slab_ring_box", ["--rows", "96", "--cols", "160", "--steps", "3", "--warmup", "1", "--depth", "5", "--period", "2", "--edge-rows", "16"]),
     ("slab_ring_box", ["--rows", "96", "--cols", "128", "--steps", "3", "--warmup", "1", "--depth", "3", "--model", "kbc", "--edge-rows", "16"]),
