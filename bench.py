@@ -309,6 +309,10 @@ def _supervise(a, argv, current):
                 code = 3
     flag = [code]
     dist.broadcast_object_list(flag, src=0)
+    dist.barrier()
+    if rank == 0 and flag[0] == 0:      # (a failed run keeps its workers' logs for the post-mortem)
+        import shutil
+        shutil.rmtree(base, ignore_errors=True)
     dist.destroy_process_group()
     return flag[0]
 

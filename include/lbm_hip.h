@@ -345,9 +345,11 @@ int lbm_cg_step_fused_part(double* pn_r, double* pn_b, const double* p_r, const 
                            const lbm_geom* g, const lbm_bc* bc, const lbm_cg_params* prm, int part,
                            int edge_rows, double* rho_r, double* rho_b, double* u, double* psi, double* s_nu,
                            lbm_stream_t s);
-/* which kernel the calling thread's last lbm_cg_step_fused launched for the INNER rectangle of the lattice: 0 the LDS tile
- * kernel (default), 41..47 the walking block (tuning "cg_strip2"), other values the strip kernels of an
- * EXPERIMENTS build; -1 before the first call.  An opt-in form the geometry does not admit falls back to the tile kernel --
+/* which kernel the calling thread's last lbm_cg_step_fused launched for the INNER rectangle of the lattice: 102 the
+ * 16 x 64 tile kernel with two nodes per thread (the default since round 4; 101, 103..109: other shapes of an EXPERIMENTS
+ * build, tuning "cg_big"), 0 the 16 x 32 tile kernel with one node per thread (tuning "cg_big" = 0, and every lattice too
+ * small for an inner rectangle), 41..47 the walking block ("cg_big" = 0 and "cg_strip2"), other values the
+ * strip kernels of an EXPERIMENTS build; -1 before the first call.  An opt-in form the geometry does not admit falls back to the tile kernel --
  * this says so (tests/test_gpu_cg.py asserts on it). */
 int lbm_cg_last_inner_form(void);
 /* driver loop context (single block); host arrays in the reference's shapes */
