@@ -1094,3 +1094,38 @@ def test_native_ring_mixed_depths_between_exchanges(lib, oracle):
             assert torch.equal(got, a), (d, float((got - a).abs().max()))
     finally:
         lib.ring_destroy(ring)
+
+
+def test_row_padded_layout_converters_and_row_copies(lib):
+    """lbm_geom.row_pitch ("row padding, hidden behind the ABI"): the pitched converters map the reference's node
+    ((r * C) + c) * 9 + q to q * plane_stride + r * row_pitch + c and back bit for bit, touch no padding, and
+    lbm_lattice_copy_rows moves row ranges between a padded ghost-row lattice and dense planes"""
+    import ctypes as ct
+    R, C, P, G = 37, 50, 64, 3
+    rng = np.random.default_rng(5)
+    f = rng.standard_normal((R, C, 9))
+    aos = torch.from_numpy(f).to("cuda:0")
+    plane = R * P + 24
+    soa = torch.full((9 * plane,), 777.0, dtype=torch.float64, device="cuda:0")
+    lib.aos_to_soa_pitched(_ptr(soa), _ptr(aos), R, C, 9, ct.c_longlong(plane), P, None)
+    torch.cuda.synchronize()
+    view = soa.cpu().numpy()
+    for q in (0, 4, 8):
+        assert np.array_equal(view[q * plane:q * plane + R * P].reshape(R, P)[:, :C], f[..., q])
+    assert int((view == 777.0).sum()) == 9 * plane - 9 * R * C          # the padding is untouched
+    back = torch.empty_like(aos)
+    lib.soa_to_aos_pitched(_ptr(back), _ptr(soa), R, C, 9, ct.c_longlong(plane), P, None)
+    torch.cuda.synchronize()
+    assert torch.equal(back, aos)
+    # rows [5, 25) of the padded planes -> rows [-2, 18) of a ghost-row lattice with another pitch -> dense planes
+    src_g = pylbm.Geom(R, C, 0, plane, P)
+    ghosted = pylbm.Geom(R, C, G, (R + 2 * G) * 58, 58)
+    lat = torch.zeros(9 * (R + 2 * G) * 58, dtype=torch.float64, device="cuda:0")
+    lib.lattice_copy_rows(_ptr(lat), ct.byref(ghosted), -2, _ptr(soa), ct.byref(src_g), 5, 20, None)
+    dense_g = pylbm.Geom(20, C, 0)
+    dense = torch.empty((9, 20, C), dtype=torch.float64, device="cuda:0")
+    lib.lattice_copy_rows(_ptr(dense), ct.byref(dense_g), 0, _ptr(lat), ct.byref(pylbm.Geom(R, C, G, (R + 2 * G) * 58, 58)), -2, 20, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(dense.cpu().numpy(), np.moveaxis(f[5:25], -1, 0))
+    with pytest.raises(pylbm.LbmError, match="row_pitch"):
+        lib.lattice_copy_rows(_ptr(dense), ct.byref(pylbm.Geom(20, C, 0, 0, C - 2)), 0, _ptr(lat), ct.byref(ghosted), 0, 20, None)
