@@ -122,9 +122,12 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
                                       {16, 32, 512, 4}};
   int n_btr = 0, n_btc = 0;
 #ifndef LBM_EXPERIMENTS
+  const bool walk_tile = false;
   const int shape = big > 0 ? 2 : 0;  // the default build ships shape 2 only (any non-zero "cg_big" selects it)
 #else
-  const int shape = big >= 1 && big <= (int)(sizeof big_shapes / sizeof big_shapes[0]) ? big : 0;
+  // 10: the WALKING tile (k_cg_walk_tile): the 16 x 64 tile advancing through chunks of "cg_walk_rows" rows
+  const bool walk_tile = big == 10;
+  const int shape = walk_tile ? 2 : (big >= 1 && big <= (int)(sizeof big_shapes / sizeof big_shapes[0]) ? big : 0);
 #endif
   if (split && shape) {
     const int* s = big_shapes[shape - 1];
@@ -171,7 +174,18 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
     // 8 x 4) but the rate the memory system delivers falls with them on some boxes: 4 x 2 is the order that is never slower
     // than the pairs (+3.6 %, +0.4 %, +0.2 % on three boxes; 8 x 2: +4.7 %, -0.3 %, -2.9 %), profiles/r04_cg_order_pmc.txt
     const int bx = tuning("cg_big_xcd", 402);
-    g_last_inner_form = 100 + shape;
+    g_last_inner_form = 100 + (walk_tile ? 10 : shape);
+#ifdef LBM_EXPERIMENTS
+    if (walk_tile) {
+      int rpc = tuning("cg_walk_rows", 128) / 16 * 16;
+      if (rpc < 16) rpc = 16;
+      const int rows_total = n_btr * 16, chunks = (rows_total + rpc - 1) / rpc;
+      const int wx = tuning("cg_walk_tile_xcd", 2);
+      if (psi) LBM_KLAUNCH((k_cg_walk_tile<true>), dim3(chunks * n_btc), dim3(512), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, rows_total, rpc, wx);
+      else LBM_KLAUNCH((k_cg_walk_tile<false>), dim3(chunks * n_btc), dim3(512), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, rows_total, rpc, wx);
+    } else
+#endif
+    {
 #define LBM_CG_BIG(BR, BC, BT, BM, BP)                                                                               \
     if (psi) LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, true>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx); \
     else LBM_KLAUNCH((k_cg_tile_mn<BR, BC, BT, BM, BP, false>), dim3(nt), dim3(BT), 0, st, pn_r, pn_b, in_r, in_b, g, cf, rho_r, rho_b, u, psi, snu, mi, ra, ca, n_btc, bx);
@@ -189,6 +203,7 @@ static int launch_cg_fused_t(double* pn_r, double* pn_b, const double* in_r, con
       default: LBM_CG_BIG(16, 64, 512, 4, true) break;   // shape 2: 16 x 64, 2 nodes per thread, the second parked in LDS
     }
 #undef LBM_CG_BIG
+    }
   } else
   // 41 .. 47: k_cg_walk -- a workgroup of TR x WC waves walking down a strip of 64 WC - 4 columns, TR rows a step
   if (sw4 >= 41 && sw4 <= 47 && rc.ic0 * TC >= 4 && 9.0 * (double)g.plane * 8.0 < 4.0e9) {  // 32-bit plane offsets

@@ -71,23 +71,10 @@ __device__ __forceinline__ double cg_snu_fast(const CgFast& c, double psi) {  //
 struct CgNode {
   double rr, rb, ux, uy, irt, psi, qx, qy;
 };
-// INTERIOR: the node and its 8 neighbours are inside the block and no boundary fix-up applies
-template <bool INTERIOR>
-__device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restrict__ in_r,
-                                          const double* __restrict__ in_b, const Geom& g,
-                                          const Bc& bc, const CgFast& cf, int gr, int gc) {
+// the reduction of cg_node on already gathered populations (fr: red, ft: blue in / colour sum out) -- ONE definition, so
+// that every kernel that gathers on its own (the walking tile issues its loads ahead of a barrier) leaves the same bits
+__device__ __forceinline__ CgNode cg_node_reduce(const double (&fr)[Q], double (&ft)[Q], const CgFast& cf) {
 #pragma clang fp contract(on)
-  double fr[Q];
-  if (INTERIOR) {
-    const long o = g.at(gr, gc);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) fr[q] = in_r[q * g.plane + (o - icx(q) * g.P - icy(q))];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) ft[q] = in_b[q * g.plane + (o - icx(q) * g.P - icy(q))];
-  } else {
-    gather_bc(fr, in_r, g, bc, gr, gc);
-    gather_bc(ft, in_b, g, bc, gr, gc);
-  }
   CgNode n;
   n.rr = (((fr[0] + fr[1]) + (fr[2] + fr[3])) + ((fr[4] + fr[5]) + (fr[6] + fr[7]))) + fr[8];
   n.rb = (((ft[0] + ft[1]) + (ft[2] + ft[3])) + ((ft[4] + ft[5]) + (ft[6] + ft[7]))) + ft[8];
@@ -104,6 +91,30 @@ __device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restr
   n.qx = qcs * n.ux;
   n.qy = qcs * n.uy;
   return n;
+}
+// plain gather of an interior node (no clamps, no wraps): the 9 + 9 pulled populations
+__device__ __forceinline__ void cg_node_gather(double (&fr)[Q], double (&ft)[Q], const double* __restrict__ in_r,
+                                               const double* __restrict__ in_b, const Geom& g, int gr, int gc) {
+  const long o = g.at(gr, gc);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) fr[q] = in_r[q * g.plane + (o - icx(q) * g.P - icy(q))];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) ft[q] = in_b[q * g.plane + (o - icx(q) * g.P - icy(q))];
+}
+// INTERIOR: the node and its 8 neighbours are inside the block and no boundary fix-up applies
+template <bool INTERIOR>
+__device__ __forceinline__ CgNode cg_node(double (&ft)[Q], const double* __restrict__ in_r,
+                                          const double* __restrict__ in_b, const Geom& g,
+                                          const Bc& bc, const CgFast& cf, int gr, int gc) {
+#pragma clang fp contract(on)
+  double fr[Q];
+  if (INTERIOR) {
+    cg_node_gather(fr, ft, in_r, in_b, g, gr, gc);
+  } else {
+    gather_bc(fr, in_r, g, bc, gr, gc);
+    gather_bc(ft, in_b, g, bc, gr, gc);
+  }
+  return cg_node_reduce(fr, ft, cf);
 }
 
 // {a0[j], a1[j]}: the taps of the stencil, in constant memory.  The loops below stay rolled (unrolled, the scheduler hoists
@@ -553,6 +564,10 @@ __global__ __launch_bounds__(NT, MINB) void k_cg_tile_mn(
     if (j + 1 < NPT) __builtin_amdgcn_sched_barrier(0);
   }
 }
+
+#ifdef LBM_EXPERIMENTS  // two-phase step, the 16 x 64 tile walking down a chunk of rows (k_cg_walk_tile): csrc/experiments/cg_walk_tile.hpp
+#include "experiments/cg_walk_tile.hpp"
+#endif
 
 #ifdef LBM_EXPERIMENTS  // two-phase step, merged frame + inner dispatch and the strip kernels of generations 1 - 4: csrc/experiments/cg_strips_1_4.hpp
 #include "experiments/cg_strips_1_4.hpp"

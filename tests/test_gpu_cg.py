@@ -313,8 +313,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
                  (61, 40), (61, 16),                                   # 61: 4 x 1 without prefetch (cg_walk_pf = 0), 4 waves per SIMD
                  (102, 64),                                            # 102: k_cg_tile_mn, 16 x 64 tiles, 2 nodes per thread (cg_big = 2: the default)
                  (102, 202), (102, 404), (102, 801), (102, 2)]         # ... with rows >= 100 / = 2: "cg_big_xcd" = rows (patch orders / pairs)
-        if lib.raw.lbm_build_has_experiments():                       # the other shapes of the round-4 sweep
-            cases += [(101, 64), (103, 64), (104, 64), (105, 64), (106, 64), (107, 64), (108, 64), (109, 64), (106, 208), (101, 303)]
+        if lib.raw.lbm_build_has_experiments():                       # the other shapes of the round-4 sweep; 110: the walking tile (cg_big = 10), rows = "cg_walk_rows" per chunk
+            cases += [(110, 16), (110, 48), (110, 128), (101, 64), (103, 64), (104, 64), (105, 64), (106, 64), (107, 64), (108, 64), (109, 64), (106, 208), (101, 303)]
         if lib.raw.lbm_build_has_experiments():                       # the strip kernels, generations 1 - 5 (make EXPERIMENTS=1)
             cases += [(1, 64), (4, 24), (2, 7), (14, 64), (12, 10), (11, 33),
                       (21, 40), (22, 9),                               # 21 / 22: k_cg_strip3 (cg_strip2 = 11 / 12)
@@ -323,7 +323,8 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
         for strip, rows in cases:
             big, strip = (strip - 100, 0) if strip > 100 else (0, strip)
             lib.set_tuning(b"cg_big", big)
-            lib.set_tuning(b"cg_big_xcd", rows if (big and (rows >= 100 or rows == 2)) else -1)
+            lib.set_tuning(b"cg_big_xcd", rows if (big and big != 10 and (rows >= 100 or rows == 2)) else -1)
+            lib.set_tuning(b"cg_walk_rows", rows if big == 10 else -1)
             lib.set_tuning(b"cg_strip", strip if strip < 10 else 0)
             lib.set_tuning(b"cg_strip2", 41 if strip == 61 else (strip - 10 if strip >= 10 else 0))
             lib.set_tuning(b"cg_walk_pf", 0 if strip == 61 else -1)
@@ -345,6 +346,7 @@ def test_cg_strip_kernel_equals_tile_kernel(lib, oracle, R, C):
     finally:
         lib.set_tuning(b"cg_big", -1)
         lib.set_tuning(b"cg_big_xcd", -1)
+        lib.set_tuning(b"cg_walk_rows", -1)
         lib.set_tuning(b"cg_strip", -1)
         lib.set_tuning(b"cg_strip2", -1)
         lib.set_tuning(b"cg_walk_pf", -1)
