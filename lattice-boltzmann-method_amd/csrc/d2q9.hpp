@@ -733,6 +733,11 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
     m.collide(f, rho, ux, uy);
   }
   // ---- store level D's row -------------------------------------------------------------------------
+  // (round 4, measured and NOT kept: the stores sit behind a branch -- warm-up rows, halo lanes -- and vmcnt counts loads and
+  // stores in issue order, so the compiler's wait for the prefetched row at the top of the next iteration is vmcnt(8): it
+  // also covers eight of the nine stores issued just before.  Taking the prefetched row over HERE, ahead of the stores (an
+  // empty asm consuming nxt[] and f[]), removes that wait from the code -- and measures 0.6 - 1.3 % SLOWER on the headline,
+  // the KBC and the cylinder windows, alternating on one box: profiles/r04_kbc_strip_width.txt)
   const int rD = rbase + i - (D - 1);  // level D's row = level 1's row - (D-1)
   if (lane_ok && rD >= R0 && rD < R1) {
     const long o = g.at(rD, 0);
@@ -758,9 +763,9 @@ __device__ __forceinline__ void sw_iteration(double (&ring)[D > 1 ? D - 1 : 1][3
 // largest multiple of 8 of them, so that every strip's stores start on a 64-byte boundary.  Measured
 // on the 8192^2 box: D = 4 at 58 columns 106 k MLUPS (every store row straddles two extra sectors:
 // partial writes), D = 5 at 56 columns 167 k.
-// A model whose collision keeps the launch VALU-bound (KBC: 400 lane-ops per update) declares
-// `static constexpr bool kFullStrips = true` and keeps all 64 - 2 (D - 1) columns: 7 % fewer strips
-// beat the aligned stores there (4096^2 KBC: 63.9 k against 60.3 k).
+// A model may declare `static constexpr bool kFullStrips = true` and keep all 64 - 2 (D - 1) columns.  KBC did in rounds 2 - 3
+// (400 lane-ops per update then: 7 % fewer strips beat the aligned stores, 63.9 k against 60.3 k) and no longer does: with
+// the collision at 196 operations the misaligned segments were what bounded the launch (kbc.hpp, 85 k against 77.5 k).
 __host__ __device__ constexpr int sw_strip_width(int D, bool full = false) {
   return full ? 64 - 2 * (D - 1) : (64 - 2 * (D - 1)) / 8 * 8;
 }

@@ -144,13 +144,19 @@ struct KbcModel {
 //    feq = w rho D_i D_j): the 25 scalings by 1/2 and 1/4 disappear into three constants of the final update;
 //  * delta_s~ = S~ - (rho D_i) D_j and delta_h~ likewise are single FMAs: feq is never formed;
 //  * gamma's two sums (eval_gamma :138-148) are sums over the 3 x 3 velocity grid of  X_i Y_j ds~ dh~  with
-//    X_i = w_i / D_i: 1/rho cancels between numerator and denominator, and the six reciprocals come out of ONE
-//    v_rcp_f64 of the product of all six D (batch inversion) -- 3 reciprocals per node instead of 8.
+//    X_i = w_i / D_i: 1/rho cancels between numerator and denominator, and (round 4) so does the product of the six
+//    1 / D: X_i ~ w_i x the other two D of its axis, no reciprocal -- 2 reciprocals per node instead of 8.
+// Round 4: 200 f64 operations + 2 v_rcp_f64 per collision (235 + 3 before): the k22 central moment is folded into H~_0, the
+// weights of gamma's sums need no reciprocal, the final update forms S~ + gamma H~ first.
 // Agreement with the reference-order model to rounding (tests/test_gpu_kbc.py states the tolerance).
 struct KbcFastModel {
   double s2, is2, hs2, qs2;  // is2 = 1 / s2 (one IEEE division on the host instead of one per node); s2 / 2, s2 / 4
   __host__ __device__ explicit KbcFastModel(double s) : s2(s), is2(1.0 / s), hs2(0.5 * s), qs2(0.25 * s) {}
-  static constexpr bool kFullStrips = true;  // VALU-bound in the sliding window: d2q9.hpp sw_strip_width
+  // Strips of 56 columns, not of all 64 - 2 (D - 1) valid ones (round 4): with 60-column strips every stored row segment starts
+  // 16 bytes off a 32-byte sector and the launch sits on a memory-side floor of 38 ps per node whatever its arithmetic (2 or 3
+  // steps, 235 or 196 operations per collision: 0.65 - 0.68 ms per 4096^2 launch); 448-byte segments run at the BGK windows'
+  // 31 ps per node (2 steps: 0.53 ms, 3 steps: 0.59 ms = 85 k instead of 77.5 k MLUPS; profiles/r04_kbc_strip_width.txt)
+  static constexpr bool kFullStrips = false;  // d2q9.hpp sw_strip_width
 
   __device__ __forceinline__ static double rcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);
@@ -176,12 +182,13 @@ struct KbcFastModel {
     const double ux2 = ux * ux, uy2 = uy * uy, uxy = ux * uy;
     // central moments (binomial shift)
     const double k20 = m20 - jx * ux, k02 = m02 - jy * uy, C5 = m11 - jx * uy;
-    const double C6 = (m21 - uy * m20) - 2.0 * ux * C5;
-    const double C7 = (m12 - ux * m02) - 2.0 * uy * C5;
-    const double C8 = ((m22 - 2.0 * (uy * m21 + ux * m12)) + (uy2 * m20 + ux2 * m02)) +
-                      (4.0 * uxy * m11 - 3.0 * (jx * ux) * uy2);
+    const double z6 = (2.0 * C5) * ux, z7 = (2.0 * C5) * uy;  // shared by C6 / C7 and the S~ block
+    const double C6 = (m21 - uy * m20) - z6;
+    const double C7 = (m12 - ux * m02) - z7;
+    // (C8, the central moment k22 = m22 - 2 (ux C7 + uy C6) - i8s - rho ux^2 uy^2 with the i8s of the S~ block below, is
+    // never formed: it enters only through H~_0 = 2 (C6 uy + C7 ux) + C8, where the first bracket cancels -- round 4)
     // S~ = M^-1 N^-1 (0,0,0,C3,C4,C5,0,0,0) / w, C3 = k20 + k02, C4 = k20 - k02
-    const double i6s = k20 * uy + 2.0 * C5 * ux, i7s = k02 * ux + 2.0 * C5 * uy;
+    const double i6s = k20 * uy + z6, i7s = k02 * ux + z7;
     const double i8s = (k02 * ux2 + k20 * uy2) + 4.0 * C5 * uxy;
     const double c5p = C5 + i8s, c5m = i8s - C5, s67 = i6s + i7s, d67 = i6s - i7s;
     const double S0 = i8s - (k20 + k02);
@@ -189,7 +196,8 @@ struct KbcFastModel {
     const double S2 = k02 - (i6s + i8s), S4 = k02 + (i6s - i8s);
     const double S5 = c5p + s67, S6 = c5m + d67, S7 = c5p - s67, S8 = c5m - d67;
     // H~ = M^-1 N^-1 (0,...,0,C6,C7,C8) / w
-    const double H0 = 2.0 * (C6 * uy + C7 * ux) + C8;
+    const double w20 = jx * ux;  // rho ux^2
+    const double H0 = (m22 - i8s) - w20 * uy2;
     const double csum = C6 + C7, cdif = C6 - C7;
     const double H1 = -(C7 + H0), H3 = C7 - H0, H2 = -(C6 + H0), H4 = C6 - H0;
     const double H5 = H0 + csum, H6 = H0 + cdif, H7 = H0 - csum, H8 = H0 - cdif;
@@ -199,18 +207,17 @@ struct KbcFastModel {
     const double Dy0 = (1.0 - cs2) - uy2, Dyp = by + uy, Dym = by - uy;
     const double rx0 = rho * Dx0, rxp = rho * Dxp, rxm = rho * Dxm;
     // delta_s~, delta_h~ (rows 5-8 of delta_h as written in the reference: "ux2 + uy" where the algebra has ux2 * uy, Q8)
-    const double qa = rho * ((ux2 + uy) - ux2 * uy), qb = rho * ((uy - ux2) + ux2 * uy);
+    // qa = rho ((ux2 + uy) - ux2 uy), qb = rho ((uy - ux2) + ux2 uy): rho uy = jy, rho ux2 = jx ux
+    const double qd = w20 - w20 * uy, qa = jy + qd, qb = jy - qd;
     const double ds0 = S0 - rx0 * Dy0, ds1 = S1 - rxp * Dy0, ds2 = S2 - rx0 * Dyp, ds3 = S3 - rxm * Dy0, ds4 = S4 - rx0 * Dym;
     const double ds5 = S5 - rxp * Dyp, ds6 = S6 - rxm * Dyp, ds7 = S7 - rxm * Dym, ds8 = S8 - rxp * Dym;
     const double dh0 = H0 - rx0 * Dy0, dh1 = H1 - rxp * Dy0, dh2 = H2 - rx0 * Dyp, dh3 = H3 - rxm * Dy0, dh4 = H4 - rx0 * Dym;
     const double dh5 = (H5 - rxp * Dyp) - qa, dh6 = (H6 - rxm * Dyp) - qa, dh7 = (H7 - rxm * Dym) - qb, dh8 = (H8 - rxp * Dym) - qb;
-    // X_i = w_i / D_i, Y_j = w_j / D_j from ONE reciprocal of the product of the six D
-    const double ax = Dxp * Dxm, px = Dx0 * ax, ay = Dyp * Dym, py = Dy0 * ay;
-    const double Rall = rcp(px * py);
-    const double Rx = Rall * py, Ry = Rall * px;
-    const double X0 = Rx * ax, hx = (0.5 * Rx) * Dx0, Xp = hx * Dxm, Xm = hx * Dxp;
-    const double Y0 = Ry * ay, hy = (0.5 * Ry) * Dy0, Yp = hy * Dym, Ym = hy * Dyp;
-    // eval_gamma :138-148: num / den = sum X_i Y_j ds~ dh~ / sum X_i Y_j dh~^2 (1 / rho cancels)
+    // X_i = w_i / D_i, Y_j = w_j / D_j enter only through the RATIO of two sums weighted by X_i Y_j: the common factor
+    // 1 / (Dx0 Dxp Dxm Dy0 Dyp Dym) cancels like 1 / rho does, X_i ~ w_i prod_{k != i} D_k needs no reciprocal (round 4)
+    const double X0 = Dxp * Dxm, hx = 0.5 * Dx0, Xp = hx * Dxm, Xm = hx * Dxp;
+    const double Y0 = Dyp * Dym, hy = 0.5 * Dy0, Yp = hy * Dym, Ym = hy * Dyp;
+    // eval_gamma :138-148: num / den = sum X_i Y_j ds~ dh~ / sum X_i Y_j dh~^2
     const double t0 = dh0 * Y0, t1 = dh1 * Y0, t3 = dh3 * Y0;
     const double t2 = dh2 * Yp, t5 = dh5 * Yp, t6 = dh6 * Yp;
     const double t4 = dh4 * Ym, t8 = dh8 * Ym, t7 = dh7 * Ym;
@@ -220,17 +227,21 @@ struct KbcFastModel {
     const double num = (X0 * n0 + Xp * np) + Xm * nm, den = (X0 * e0 + Xp * ep) + Xm * em;
     const double gamma = is2 - (1.0 - is2) * (num * rcp(den));
     // relaxed populations: f - s2 w (S~ - cs2 rho G~) - gamma s2 w (H~ - cs4 rho V8~), V8~ = (1, -1 x 4, 1 x 4)
-    const double g2 = ux2 + uy2, gm = g2 - 1.0, us = ux + uy, ud = ux - uy;
-    const double cr = cs2 * rho, hr = cs4 * rho, gs = gamma * s2, hgs = gamma * hs2, qgs = gamma * qs2;
-    f[0] = (f[0] - s2 * (S0 - cr * (g2 - 2.0))) - gs * (H0 - hr);
-    f[1] = (f[1] - hs2 * (S1 + cr * (gm + ux))) - hgs * (H1 + hr);
-    f[2] = (f[2] - hs2 * (S2 + cr * (gm + uy))) - hgs * (H2 + hr);
-    f[3] = (f[3] - hs2 * (S3 + cr * (gm - ux))) - hgs * (H3 + hr);
-    f[4] = (f[4] - hs2 * (S4 + cr * (gm - uy))) - hgs * (H4 + hr);
-    f[5] = (f[5] - qs2 * (S5 - cr * (g2 + us))) - qgs * (H5 - hr);
-    f[6] = (f[6] - qs2 * (S6 - cr * (g2 - ud))) - qgs * (H6 - hr);
-    f[7] = (f[7] - qs2 * (S7 - cr * (g2 - us))) - qgs * (H7 - hr);
-    f[8] = (f[8] - qs2 * (S8 - cr * (g2 + ud))) - qgs * (H8 - hr);
+    //                    = f - s2 w ((S~ + gamma H~) - cs2 rho (G~ + (gamma / 3) V8~))          (cs4 = cs2 / 3)
+    // (round 4: four operations per population instead of five, gamma s2 w and cs4 rho are never formed: 226 f64
+    // operations per collision instead of 235)
+    const double g2 = ux2 + uy2, us = ux + uy, ud = ux - uy;
+    const double cr = cs2 * rho, g3 = cs2 * gamma;
+    const double k5 = g2 + g3, k1 = k5 - 1.0, k0 = k5 - 2.0;
+    f[0] = f[0] - s2 * ((S0 + gamma * H0) - cr * k0);
+    f[1] = f[1] - hs2 * ((S1 + gamma * H1) + cr * (k1 + ux));
+    f[2] = f[2] - hs2 * ((S2 + gamma * H2) + cr * (k1 + uy));
+    f[3] = f[3] - hs2 * ((S3 + gamma * H3) + cr * (k1 - ux));
+    f[4] = f[4] - hs2 * ((S4 + gamma * H4) + cr * (k1 - uy));
+    f[5] = f[5] - qs2 * ((S5 + gamma * H5) - cr * (k5 + us));
+    f[6] = f[6] - qs2 * ((S6 + gamma * H6) - cr * (k5 - ud));
+    f[7] = f[7] - qs2 * ((S7 + gamma * H7) - cr * (k5 - us));
+    f[8] = f[8] - qs2 * ((S8 + gamma * H8) - cr * (k5 + ud));
   }
 };
 
