@@ -438,6 +438,10 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
       launched = true;
     }
   }
+  // (round 4, measured and not kept: the BGK window with its ring in wave-private LDS like the KBC window -- k_stream_collide_sw<BgkFastModel,
+  // 5, 2, nt, LDSR>: 1119 instead of 1378 VALU instructions per three iterations (no lane shifts, no AGPR copies), 169 registers, six
+  // waves per CU by LDS.  8192^2, alternating on one box at the 1400 W limit: 160.8 / 161.4 / 160.8 k with the register ring, 152.6 /
+  // 152.8 / 152.3 k with the LDS ring at a 100 MHz lower clock.  profiles/r04_bgk_ldsring_ab.txt)
   if (!launched) {
 #define LBM_SW(DV, WV)                                                                            \
   if (depth == DV && waves == WV) {                                                               \
