@@ -770,7 +770,7 @@ class Secondary:
         self._placement = torch.empty(int(os.environ.get("LBM_BENCH_PREALLOC_MB", "0")) << 20, dtype=torch.uint8, device=dev)
         if which == "kbc":      # config 3: ulbm_double_shear_flow.cpp:42-63 at 4096^2 (s2 = omega, nu = 1.70766666e-4)
             R, C = 4096, int(os.environ.get("LBM_BENCH_KBC_COLS", "4096"))   # (other widths: a probe of row-stride effects)
-            self.unit = int(lib.raw.lbm_get_tuning(b"kbc_depth")) or 3
+            self.unit = int(lib.raw.lbm_get_tuning(b"kbc_depth")) or 4
             self.kernel = f"k_stream_collide_sw<KbcFastModel,{self.unit},2,nt>"
             self.bytes_per_update, self.config = 144.0, "ulbm_double_shear_flow 4096x4096 KBC (entropic MRT), periodic"
             self.sv = pylbm.Solver(lib, pylbm.MODEL_KBC, R, C, pylbm.KbcParams(1.0 / (0.5 + 3 * 1.70766666e-4)))

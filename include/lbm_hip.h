@@ -699,7 +699,7 @@ int lbm_solver_checkpoint_load(lbm_solver* sv, const char* path);
  * implementation switches, which select between a model's two collision implementations:
  *   "bgk_fast", "kbc_fast", "cg_fused" (default 1): the reassociated collision / the one-launch
  *   two-phase step; 0 = the reference's operation order, bit-identical to the CPU oracle.
- * Further keys: "kbc_depth" (steps lbm_solver_step fuses per launch for KBC, default 3), "cg_tile"
+ * Further keys: "kbc_depth" (steps lbm_solver_step fuses per launch for KBC, default 4; 3 with walls), "cg_tile"
  * (0: 8x32, 1: 16x32, 2: 8x64, 3 / 4 [default]: 16x32 budgeted for 3 / 4 waves per SIMD, 5: 32x32, 6: 16x64), "cg_xcd" (0: hardware order; 1: XCD-contiguous eighths; 2 [default] / 4 / 8: groups of that many
  * column-neighbour tiles per XCD), "cg_strip" (0 [default]: LDS tile kernel; 1/2/4:
  * column-strip sliding-window kernel with that many waves per workgroup, "cg_rows" rows per chunk),

@@ -160,6 +160,7 @@ static int launch_stream_collide_sw_kbc(const char* fn, double* pn, const double
   const bool ldsr = tuning("sw_ldsring", 1) != 0;
   if (depth == 2 && ldsr) LBM_KBC_SW(KbcFastModel, 2, 2, true, false, false, true)
   else if (depth == 3 && ldsr) LBM_KBC_SW(KbcFastModel, 3, 2, true, false, false, true)
+  else if (depth == 4 && ldsr) LBM_KBC_SW(KbcFastModel, 4, 2, true, false, false, true)
   else if (depth == 2) LBM_KBC_SW(KbcFastModel, 2, 2, true)
   else if (depth == 3) LBM_KBC_SW(KbcFastModel, 3, 2, true)
   else LBM_KBC_SW(KbcFastModel, 4, 2, true)

@@ -436,13 +436,14 @@ static bool solver_can_fuse_steps(const lbm_solver* sv) {
 int lbm_solver_step(lbm_solver* sv, int n, int record_moments) {
   LBM_REQUIRE(sv && n >= 0, "lbm_solver_step: bad argument (n=%d)", n);
   // steps fused per launch: 5 on periodic BGK blocks, 4 when the window carries walls (its register
-  // ring plus the fix-ups: 365 VGPRs at 4, 442 at 5; measured 104-108 k vs 94-103 k MLUPS), 3 for KBC
+  // ring plus the fix-ups: 365 VGPRs at 4, 442 at 5; measured 104-108 k vs 94-103 k MLUPS); KBC: 4 on periodic blocks (LDS ring,
+  // round 4: 87.4 - 89.6 k against 86.0 k with 3 at 4096^2, the launch being power-bound the saved bytes count), 3 with walls
   const lbm_bc& bb = sv->bc;
   const bool walled = bc_is_wall(bb.row_lo) || bc_is_wall(bb.row_hi) || bc_is_wall(bb.col_lo) || bc_is_wall(bb.col_hi);
   // (the reference-order BGK collision on a PERIODIC block carries more live values per level: 4 steps per launch read 132.6 k MLUPS at
   // 8192^2 against 127.1 k with 5, 99.0 k with 3, 120.3 k with 6; the reassociated default 5: 177 / 171 / 143 k at 5 / 6 / 4)
   const bool ref_order_bgk = sv->model == LBM_MODEL_BGK && !bgk_uses_fast_model(&sv->bgk, &sv->bc);
-  int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 3) : tuning("solver_depth", ref_order_bgk && !sv->ibm && !walled && !bb.pressure_rows ? 4 : 5);
+  int max_depth = sv->model == LBM_MODEL_KBC ? tuning("kbc_depth", 4) : tuning("solver_depth", ref_order_bgk && !sv->ibm && !walled && !bb.pressure_rows ? 4 : 5);
   if (walled && sv->model == LBM_MODEL_BGK && max_depth > tuning("solver_depth_walls", 5)) max_depth = tuning("solver_depth_walls", 5);
   if (walled && sv->model == LBM_MODEL_KBC && max_depth > 3) max_depth = 3;
   for (int i = 0; i < n;) {

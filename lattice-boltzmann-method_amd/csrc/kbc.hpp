@@ -168,7 +168,7 @@ struct KbcFastModel {
     // end -- identical in every kernel this model is inlined into (single-step, sliding-window,
     // edge pass), which contract(fast) (back-end, context dependent) does not guarantee
 #pragma clang fp contract(on)
-    constexpr double cs2 = 1.0 / 3.0, cs4 = 1.0 / 9.0;
+    constexpr double cs2 = 1.0 / 3.0;
     // raw moments (butterfly)
     const double a = f[1] + f[3], b = f[2] + f[4], d57 = f[5] + f[7], d68 = f[6] + f[8];
     const double e57 = f[5] - f[7], e68 = f[6] - f[8];
