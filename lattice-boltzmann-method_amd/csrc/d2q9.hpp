@@ -867,8 +867,8 @@ __device__ __forceinline__ void sw_wave_body(double* __restrict__ pn, const doub
   }
 }
 
-template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false, bool LDSR = false, bool LOOSE = false>
-__global__ __launch_bounds__(64 * WAVES, (LDSR ? 2 : (WAVES == 4 && !LOOSE ? sw_waves_per_simd(D) : 1))) void k_stream_collide_sw(
+template <class Model, int D, int WAVES, bool NT_STORE, bool HAS_BC = false, bool PF2 = false, bool LDSR = false>
+__global__ __launch_bounds__(64 * WAVES, (LDSR ? 2 : (WAVES == 4 ? sw_waves_per_simd(D) : 1))) void k_stream_collide_sw(
     double* __restrict__ pn, const double* __restrict__ po, Geom g, Model m, int row_begin,
     int row_end, int rows_per_chunk, int strips, int n_waves, int xcd_group, Bc bc = Bc{}, int strip0 = 0,
     int chunk_stride = 0) {

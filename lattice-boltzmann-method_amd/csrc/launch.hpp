@@ -366,9 +366,7 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
   const int W = sw_strip_width(depth, sw_full_strips<Model>::value);
   const int strips = (g.C + W - 1) / W;
   LBM_REQUIRE((long)strips * ((nrows + 31) / 32) < (1L << 30), "%s: lattice too large for one launch", fn);
-  const int nt = tuning("nt", 3) & 2, waves_req = tuning("sw_waves", default_waves);
-  const bool loose4 = waves_req == 14 && std::is_same<Model, BgkFastModel>::value && depth == 5 && nt;
-  const int waves = waves_req == 14 ? default_waves : waves_req;
+  const int nt = tuning("nt", 3) & 2, waves = tuning("sw_waves", default_waves);
   int rpc = 0, n_waves = 0;
   // sw_rows > 0: fixed chunk height; unset: chosen per kernel instance from its resident wave slots
   auto plan = [&](const void* kernel, int block_threads) {
@@ -428,16 +426,9 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
     }
   }
 #endif  // LBM_EXPERIMENTS
-  if constexpr (std::is_same<Model, BgkFastModel>::value) {
-    // probe: FOUR adjacent strips per workgroup, register budget uncapped (one wave per SIMD): the 128-byte lines neighbouring
-    // strips share are fetched by waves of ONE compute unit
-    if (!launched && loose4) {
-      plan((const void*)k_stream_collide_sw<Model, 5, 4, true, false, false, false, true>, 256);
-      LBM_KLAUNCH((k_stream_collide_sw<Model, 5, 4, true, false, false, false, true>), dim3((n_waves + 3) / 4), dim3(256), 0, st, pn, po, g, m,
-                  row_begin, row_end_k, rpc, strips, n_waves, tuning("sw_xcd", 0), Bc{}, 0, chunk_stride);
-      launched = true;
-    }
-  }
+  // (rounds 3 - 4, measured and removed: FOUR adjacent strips per workgroup with the register budget uncapped, so that the 128-byte lines
+  // neighbouring strips share are fetched by waves of one compute unit -- 177.7 / 177.4 k against 177.0 / 176.9 k for the 2-wave blocks,
+  // alternating on one box: within noise.  The capped 4-wave blocks spill at 5 steps: 85 k.)
   // (round 4, measured and not kept: the BGK window with its ring in wave-private LDS like the KBC window -- k_stream_collide_sw<BgkFastModel,
   // 5, 2, nt, LDSR>: 1119 instead of 1378 VALU instructions per three iterations (no lane shifts, no AGPR copies), 169 registers, six
   // waves per CU by LDS.  8192^2, alternating on one box at the 1400 W limit: 160.8 / 161.4 / 160.8 k with the register ring, 152.6 /
