@@ -926,6 +926,9 @@ __global__ __launch_bounds__(128, 1) void k_stream_collide_sw_walls(double* __re
 #ifdef LBM_EXPERIMENTS  // sliding window on paired strips (k_stream_collide_swp): csrc/experiments/sw_paired_strips.hpp
 #include "experiments/sw_paired_strips.hpp"
 #endif
+#ifdef LBM_EXPERIMENTS  // sliding window with two columns per lane (k_stream_collide_sw2): csrc/experiments/sw_two_columns.hpp
+#include "experiments/sw_two_columns.hpp"
+#endif
 
 // Edge pass: recompute the boundary nodes (rows 0 / R-1 where they carry a fix-up, columns
 // 0 / C-1 where they do) with the full boundary gather and overwrite what the interior

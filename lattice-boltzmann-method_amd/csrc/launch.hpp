@@ -418,6 +418,25 @@ int launch_stream_collide_sw(const char* fn, double* pn, const double* po, const
     }
   }
   if constexpr (std::is_same<Model, BgkFastModel>::value) {
+    // two columns per lane (d2q9.hpp / experiments/sw_two_columns.hpp): 16-byte accesses need even columns, pitch and plane stride
+    if (!launched && tuning("sw_cols2", 0) && (depth == 5 || depth == 6) && nt && g.C % 2 == 0 && g.P % 2 == 0 && g.plane % 2 == 0 &&
+        ((uintptr_t)pn % 16) == 0 && ((uintptr_t)po % 16) == 0) {
+      const int W2 = sw2_strip_width(depth), strips2 = (g.C + W2 - 1) / W2;
+      int rows = tuning("sw_rows", -1);
+      const void* kp = depth == 5 ? (const void*)k_stream_collide_sw2<Model, 5, true> : (const void*)k_stream_collide_sw2<Model, 6, true>;
+      if (second_begin >= 0) rows = nrows;
+      else if (rows <= 0) {
+        const long slots = sw_wave_slots(kp, 128);
+        rows = slots > 0 ? sw_pick_rows(nrows, strips2, depth, slots) : 64;
+      }
+      if (rows > nrows) rows = nrows;
+      const int nw = second_begin >= 0 ? 2 * strips2 : strips2 * ((nrows + rows - 1) / rows);
+      if (depth == 5) LBM_KLAUNCH((k_stream_collide_sw2<Model, 5, true>), dim3((nw + 1) / 2), dim3(128), 0, st, pn, po, g, m, row_begin, row_end_k, rows, strips2, nw, chunk_stride);
+      else LBM_KLAUNCH((k_stream_collide_sw2<Model, 6, true>), dim3((nw + 1) / 2), dim3(128), 0, st, pn, po, g, m, row_begin, row_end_k, rows, strips2, nw, chunk_stride);
+      launched = true;
+    }
+  }
+  if constexpr (std::is_same<Model, BgkFastModel>::value) {
     if (!launched && tuning("sw_pf2", 0) && depth == 5 && waves == 2 && nt) {  // level-1 rows prefetched two iterations ahead
       plan((const void*)k_stream_collide_sw<Model, 5, 2, true, false, true>, 128);
       LBM_KLAUNCH((k_stream_collide_sw<Model, 5, 2, true, false, true>), dim3((n_waves + 1) / 2), dim3(128), 0, st, pn, po, g, m,

@@ -129,7 +129,7 @@ class Lib:
         return int(self.raw.lbm_default_plane_pad(R, C))
 
     def reset_tuning(self):
-        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd", b"kbc_fast", b"kbc_depth", b"bgk_fast", b"cg_strip", b"cg_rows", b"cg_split", b"sw_split", b"solver_depth_walls", b"ibm_depth", b"ibm_gate", b"bgk_fast_delta", b"pressure_depth", b"halo_grid", b"cg_strip2", b"cg_rows2", b"sw_pair", b"sw_pf2", b"cg_strip_xcd", b"cg_merge", b"cg_frame_beside", b"ring_period", b"ibm_step_opt", b"ibm_step_split", b"ibm_step_chain", b"ibm_box", b"ibm_box_overlap", b"bg_priority", b"ibm_chain_kernel", b"ibm_chain_wgs", b"ibm_box_sole", b"sw_ldsring", b"ring_ipc_timeout_ms", b"cg_big", b"cg_big_xcd", b"ring_cg_parts", b"ring_ipc_force_cached", b"ring_ipc_cached_ok", b"row_pad", b"cg_walk_rows", b"cg_walk_tile_xcd"):
+        for k in (b"variant", b"nt", b"grid_cap", b"block", b"rows", b"xcd_swizzle", b"tb_rows", b"tb_block", b"tb_order", b"sw_rows", b"sw_waves", b"solver_depth", b"cg_fused", b"cg_tile", b"cg_xcd", b"kbc_fast", b"kbc_depth", b"bgk_fast", b"cg_strip", b"cg_rows", b"cg_split", b"sw_split", b"solver_depth_walls", b"ibm_depth", b"ibm_gate", b"bgk_fast_delta", b"pressure_depth", b"halo_grid", b"cg_strip2", b"cg_rows2", b"sw_pair", b"sw_pf2", b"cg_strip_xcd", b"cg_merge", b"cg_frame_beside", b"ring_period", b"ibm_step_opt", b"ibm_step_split", b"ibm_step_chain", b"ibm_box", b"ibm_box_overlap", b"bg_priority", b"ibm_chain_kernel", b"ibm_chain_wgs", b"ibm_box_sole", b"sw_ldsring", b"ring_ipc_timeout_ms", b"cg_big", b"cg_big_xcd", b"ring_cg_parts", b"ring_ipc_force_cached", b"ring_ipc_cached_ok", b"row_pad", b"cg_walk_rows", b"cg_walk_tile_xcd", b"sw_cols2"):
             self.set_tuning(k, -1)
 
 

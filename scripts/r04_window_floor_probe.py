@@ -47,8 +47,8 @@ for R, C in shapes:
         while time.perf_counter() - t0 < 0.5:  # warm the clocks
             run(lib.bgk_stream_collide_xn, pylbm.BgkParams(omega=1.2), 3, a, b, g, R, reps=4)
         row = {"R": R, "C": C, "row_pitch": P}
-        for name, fn, prm, ns in (("bgk", lib.bgk_stream_collide_xn, pylbm.BgkParams(omega=1.2), (2, 3, 5)),
-                                  ("kbc", lib.kbc_stream_collide_xn, pylbm.KbcParams(s2=1.6), (2, 3))):
+        for name, fn, prm, ns in (("bgk", lib.bgk_stream_collide_xn, pylbm.BgkParams(omega=1.2), tuple(int(v) for v in os.environ.get("PROBE_BGK_N", "2,3,5").split(","))),
+                                  ("kbc", lib.kbc_stream_collide_xn, pylbm.KbcParams(s2=1.6), tuple(int(v) for v in os.environ.get("PROBE_KBC_N", "2,3").split(",")))):
             for n in ns:
                 t = run(fn, prm, n, a, b, g, R)
                 row["%s_x%d" % (name, n)] = {"ms": round(t * 1e3, 4), "ps_per_node": round(t / (R * C) * 1e12, 2),
