@@ -176,7 +176,7 @@ def test_ulbm_poiseuille_preset_vs_oracle_and_reference(lib, oracle, H, W):
 def test_kbc_multi_step_launches_equal_single_steps(lib, oracle):
     """lbm_kbc_stream_collide_xn (register sliding window, reassociated collision): D steps in one
     launch == D single-step launches bit for bit (same per-node arithmetic), D = 2, 3, 4; and the
-    solver context, which fuses 3 steps per launch by default, against the oracle."""
+    solver context, which fuses 4 steps per launch by default (21 = 5 x 4 + 1), against the oracle."""
     rng = np.random.default_rng(21)
     R, C = 96, 192
     rho = 1 + 0.01 * rng.standard_normal((R, C))
