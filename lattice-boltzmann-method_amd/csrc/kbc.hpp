@@ -146,7 +146,7 @@ struct KbcModel {
 //  * gamma's two sums (eval_gamma :138-148) are sums over the 3 x 3 velocity grid of  X_i Y_j ds~ dh~  with
 //    X_i = w_i / D_i: 1/rho cancels between numerator and denominator, and (round 4) so does the product of the six
 //    1 / D: X_i ~ w_i x the other two D of its axis, no reciprocal -- 2 reciprocals per node instead of 8.
-// Round 4: 200 f64 operations + 2 v_rcp_f64 per collision (235 + 3 before): the k22 central moment is folded into H~_0, the
+// Round 4: 189 f64 operations + 2 v_rcp_f64 per collision (235 + 3 before): the k22 central moment is folded into H~_0, the
 // weights of gamma's sums need no reciprocal, the final update forms S~ + gamma H~ first.
 // Agreement with the reference-order model to rounding (tests/test_gpu_kbc.py states the tolerance).
 struct KbcFastModel {
@@ -174,12 +174,12 @@ struct KbcFastModel {
     const double e57 = f[5] - f[7], e68 = f[6] - f[8];
     const double m22 = d57 + d68, m11 = d57 - d68, m21 = e57 + e68, m12 = e57 - e68;
     const double m20 = a + m22, m02 = b + m22;
-    rho = (f[0] + a) + (b + m22);
+    rho = (f[0] + b) + m20;
     const double jx = (f[1] - f[3]) + m12, jy = (f[2] - f[4]) + m21;
     const double irho = rcp(rho);
     ux = jx * irho;
     uy = jy * irho;
-    const double ux2 = ux * ux, uy2 = uy * uy, uxy = ux * uy;
+    const double ux2 = ux * ux, uy2 = uy * uy;
     // central moments (binomial shift)
     const double k20 = m20 - jx * ux, k02 = m02 - jy * uy, C5 = m11 - jx * uy;
     const double z6 = (2.0 * C5) * ux, z7 = (2.0 * C5) * uy;  // shared by C6 / C7 and the S~ block
@@ -189,11 +189,12 @@ struct KbcFastModel {
     // never formed: it enters only through H~_0 = 2 (C6 uy + C7 ux) + C8, where the first bracket cancels -- round 4)
     // S~ = M^-1 N^-1 (0,0,0,C3,C4,C5,0,0,0) / w, C3 = k20 + k02, C4 = k20 - k02
     const double i6s = k20 * uy + z6, i7s = k02 * ux + z7;
-    const double i8s = (k02 * ux2 + k20 * uy2) + 4.0 * C5 * uxy;
+    const double i8s = ux * i7s + uy * i6s;  // = k02 ux^2 + k20 uy^2 + 4 C5 ux uy
     const double c5p = C5 + i8s, c5m = i8s - C5, s67 = i6s + i7s, d67 = i6s - i7s;
-    const double S0 = i8s - (k20 + k02);
-    const double S1 = k20 - (i7s + i8s), S3 = k20 + (i7s - i8s);
-    const double S2 = k02 - (i6s + i8s), S4 = k02 + (i6s - i8s);
+    const double A8 = k20 - i8s, B8 = k02 - i8s;
+    const double S0 = -(A8 + k02);
+    const double S1 = A8 - i7s, S3 = A8 + i7s;
+    const double S2 = B8 - i6s, S4 = B8 + i6s;
     const double S5 = c5p + s67, S6 = c5m + d67, S7 = c5p - s67, S8 = c5m - d67;
     // H~ = M^-1 N^-1 (0,...,0,C6,C7,C8) / w
     const double w20 = jx * ux;  // rho ux^2
@@ -228,8 +229,7 @@ struct KbcFastModel {
     const double gamma = is2 - (1.0 - is2) * (num * rcp(den));
     // relaxed populations: f - s2 w (S~ - cs2 rho G~) - gamma s2 w (H~ - cs4 rho V8~), V8~ = (1, -1 x 4, 1 x 4)
     //                    = f - s2 w ((S~ + gamma H~) - cs2 rho (G~ + (gamma / 3) V8~))          (cs4 = cs2 / 3)
-    // (round 4: four operations per population instead of five, gamma s2 w and cs4 rho are never formed: 226 f64
-    // operations per collision instead of 235)
+    // (round 4: four operations per population instead of five, gamma s2 w and cs4 rho are never formed)
     const double g2 = ux2 + uy2, us = ux + uy, ud = ux - uy;
     const double cr = cs2 * rho, g3 = cs2 * gamma;
     const double k5 = g2 + g3, k1 = k5 - 1.0, k0 = k5 - 2.0;
